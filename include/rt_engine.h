@@ -1,0 +1,158 @@
+/*
+ * C ABI of the MI355X ray-intersection + photon-gather engine
+ * (librt_engine.so).  Plain pointers and sizes only.  Every pointer marked
+ * "device" is a device address valid on the current HIP device; streams are
+ * hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the reference's repository root).
+ *
+ * Status codes: 0 (RT_SUCCESS) on success; a positive value is the hipError_t
+ * of the first failing HIP call (the reference returns the first failing
+ * cudaError_t, src/photon_grid.cu:53-82); negative values are RT_ERROR_*.
+ */
+#ifndef RT_ENGINE_H
+#define RT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int rt_status;
+#define RT_SUCCESS 0
+#define RT_ERROR_INVALID_VALUE (-1)
+#define RT_ERROR_OUT_OF_RANGE (-2)
+
+/* Message of the most recent failure on the calling host thread. */
+const char* rt_last_error(void);
+/* Printable name of a status code (cudaGetErrorString in src/renderer.cpp:30-33). */
+const char* rt_status_string(rt_status status);
+
+/* ------------------------------------------------------------------------
+ * Photon hash grid — replaces src/photon_grid.hpp:12-20 (src/photon_grid.cu)
+ * ------------------------------------------------------------------------ */
+
+/* Scratch bytes needed to sort up to maxCount photons into bucketCount buckets. */
+size_t rt_photon_grid_scratch_bytes(uint32_t maxCount, uint32_t bucketCount);
+
+/* photonScanStorage(bucketCount), src/photon_grid.hpp:12.  The reference sizes
+ * its photon buffer at twice the bucket count (src/renderer.cpp:533-534), so
+ * this returns rt_photon_grid_scratch_bytes(2 * bucketCount, bucketCount). */
+size_t rt_photon_scan_storage(uint32_t bucketCount);
+
+/* buildPhotonGrid(...), src/photon_grid.hpp:17-20.  All pointers are device
+ * pointers allocated by the caller: counts and offsets hold bucketCount + 1
+ * uint32, sorted holds count photons.  On return offsets[b]..offsets[b+1]
+ * delimits bucket b inside sorted and counts has been clobbered.  Photons of
+ * one bucket keep their input order (the reference leaves the order to an
+ * atomic race, src/photon_grid.cu:36).  bucketCount must be a power of two.
+ * If scanBytes is smaller than rt_photon_grid_scratch_bytes(count,
+ * bucketCount) the library uses a cached workspace of its own.  count == 0 is
+ * legal.  Runs on the default stream and synchronises the device before
+ * returning (src/photon_grid.cu:82). */
+rt_status rt_build_photon_grid(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                               uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted);
+
+/* Same work enqueued on `stream` without the final synchronisation. */
+rt_status rt_build_photon_grid_async(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                                     uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes,
+                                     rt_photon* sorted, void* stream);
+
+/* photonBucket(photonCell(p, cellSize), bucketCount) for n packed float3
+ * device positions (src/photon_hash.cuh:10-24) -> keys (device, n uint32). */
+rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uint32_t bucketCount, uint32_t* keys,
+                         void* stream);
+
+/* Radius gather, the loop of causticLighting() in src/device.cu:729-762.  For
+ * each of n queries (packed float3 device arrays qpos, qnormal) writes the
+ * flux sum over photons with d^2 < r^2 and dot(n_photon, n_query) >= 0.7,
+ * weight 1 - d^2/r^2, visiting the 27 neighbour cells in the reference's
+ * z, y, x order with repeated buckets skipped.  The caller applies
+ * baseColor * diffuseWeight * 2 / (pi r^2 pi) (src/device.cu:763-765). */
+rt_status rt_photon_gather(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount, float radius,
+                           const float* qpos, const float* qnormal, uint32_t n, float* flux, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Acceleration structures — replace the OptiX GAS / IAS builds of
+ * src/renderer.cpp:343-396 and :398-434
+ * ------------------------------------------------------------------------ */
+
+typedef struct rt_blas rt_blas;   /* per-geometry BVH (GAS equivalent) */
+typedef struct rt_scene rt_scene; /* top level over instances (IAS equivalent) */
+
+/* optixAccelBuild over one triangle geometry (src/renderer.cpp:366-393):
+ * float3 positions at `vertexStride` bytes (64 for rt_gpu_vertex) in a device
+ * buffer, uint32 index triplets in a device buffer.  The buffers are read
+ * during the build only.  Synchronises `stream` before returning. */
+rt_status rt_blas_build(const void* vertices, uint32_t vertexCount, uint32_t vertexStride, const uint32_t* indices,
+                        uint32_t triangleCount, void* stream, rt_blas** out);
+void rt_blas_destroy(rt_blas* blas);
+
+/* OptixInstance as filled in src/renderer.cpp:400-412 (host memory). */
+typedef struct rt_instance_desc {
+    float transform[12];   /* object->world, row-major 3x4 */
+    uint32_t instanceId;   /* reported in hits */
+    uint32_t geometry;     /* sbtOffset upstream: index of the geometry record */
+    const rt_blas* blas;   /* traversableHandle upstream */
+} rt_instance_desc;
+
+/* optixAccelBuild over instances (src/renderer.cpp:414-432).  `instances` is
+ * host memory.  The BLASes must outlive the scene. */
+rt_status rt_scene_build(const rt_instance_desc* instances, uint32_t instanceCount, void* stream, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+/* The 8-byte value stored in rt_launch_params.scene (src/gpu_shared.hpp:117). */
+uint64_t rt_scene_handle(const rt_scene* scene);
+/* world->object 3x4 (row-major) the engine uses for instance `index`. */
+rt_status rt_scene_instance_inverse(const rt_scene* scene, uint32_t index, float* out12);
+
+typedef struct rt_bvh_stats {
+    uint64_t nodeCount;       /* wide nodes, all levels */
+    uint64_t nodeBytes;
+    uint64_t triangleCount;
+    uint64_t triangleBytes;
+    uint32_t instanceCount;
+    uint32_t maxDepth;
+    float buildMilliseconds;  /* device time of the last build */
+} rt_bvh_stats;
+rt_status rt_blas_stats(const rt_blas* blas, rt_bvh_stats* out);
+rt_status rt_scene_stats(const rt_scene* scene, rt_bvh_stats* out);
+
+/* ------------------------------------------------------------------------
+ * Ray queries — replace trace() (src/device.cu:388-397) and the occlusion use
+ * of it in visible() (src/device.cu:548-559)
+ * ------------------------------------------------------------------------ */
+
+/* Result of one closest-hit query: t, the barycentric weights of vertex 1 and
+ * vertex 2 (optixGetTriangleBarycentrics, src/device.cu:1085), the
+ * geometry-local primitive index (0xffffffff and t = -1 on a miss). */
+typedef struct rt_ray_hit {
+    float t, u, v;
+    uint32_t primitive;
+} rt_ray_hit;
+
+/* n rays as two device arrays of float4: (origin, tmin) and (direction, tmax).
+ * A hit has tmin < t <= tmax; the closest hit is the smallest t, exact ties
+ * going to the lowest (instance, primitive).  instance[i] = instanceId or
+ * 0xffffffff. */
+rt_status rt_trace_closest(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax,
+                           uint32_t n, rt_ray_hit* hits, uint32_t* instance, void* stream);
+
+/* occluded[i] = 1 iff some triangle has tmin < t <= tmax. */
+rt_status rt_trace_any(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax, uint32_t n,
+                       uint8_t* occluded, void* stream);
+
+/* Per-launch traversal counters accumulated by the *_counted variants:
+ * [0] rays, [1] wide nodes visited, [2] triangles tested, [3] instances entered. */
+rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* originTmin,
+                                   const rt_float4* directionTmax, uint32_t n, rt_ray_hit* hits, uint32_t* instance,
+                                   uint64_t* counters4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ENGINE_H */

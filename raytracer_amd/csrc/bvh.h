@@ -1,0 +1,85 @@
+// Acceleration-structure layout shared by the builder and the traversal kernels.
+//
+// Two levels, as the reference's IAS over GAS (renderer.cpp:343-434): a
+// top-level tree over instances and one bottom-level tree per geometry, both
+// made of the same 8-wide node with child boxes quantised to 8 bits per bound.
+#pragma once
+
+#include "common.h"
+
+namespace rt {
+
+constexpr int kWide = 8;          // children per node
+constexpr int kMaxLeaf = 4;       // triangles per leaf child
+constexpr uint32_t kNoHit = 0xffffffffU;
+
+// 80 bytes, five 16-byte loads per visit.
+//   child box = origin + q * 2^(exp - 127) per axis, lo rounded down, hi up.
+//   imask bit i set  : child i is a node, index childBase + meta[i]
+//   imask bit i clear: meta[i] >> 5 = item count (0 = empty slot),
+//                      meta[i] & 31 = first item relative to primBase
+//   items are triangles in a bottom-level tree, instances in the top level.
+struct alignas(16) WideNode {
+    float origin[3];
+    uint8_t exp[3];
+    uint8_t imask;
+    uint32_t childBase;
+    uint32_t primBase;
+    uint8_t meta[kWide];
+    uint8_t qlo[3][kWide];
+    uint8_t qhi[3][kWide];
+};
+static_assert(sizeof(WideNode) == 80, "wide node is 80 bytes");
+
+// A triangle as the traversal reads it: three 16-byte loads.
+struct alignas(16) PackedTriangle {
+    float v0[3];
+    uint32_t primitive;  // geometry-local triangle index
+    float v1[3];
+    uint32_t pad1;
+    float v2[3];
+    uint32_t pad2;
+};
+static_assert(sizeof(PackedTriangle) == 48, "packed triangle is 48 bytes");
+
+// Top-level leaf item: 80 bytes.
+struct alignas(16) InstanceRecord {
+    float toObject[12];           // world->object, row-major 3x4
+    const WideNode* nodes;        // bottom-level root
+    const PackedTriangle* triangles;
+    uint32_t instanceId;
+    uint32_t geometry;
+    uint32_t pad[2];
+};
+static_assert(sizeof(InstanceRecord) == 80, "instance record is 80 bytes");
+
+struct Aabb {
+    float lo[3];
+    float hi[3];
+};
+
+}  // namespace rt
+
+struct rt_blas {
+    int device = 0;
+    rt::WideNode* nodes = nullptr;
+    rt::PackedTriangle* triangles = nullptr;
+    uint64_t nodeCount = 0;
+    uint64_t triangleCount = 0;
+    uint32_t depth = 0;
+    rt::Aabb bounds{};            // object-space root bounds (host copy)
+    float buildMilliseconds = 0.0f;
+};
+
+struct rt_scene {
+    int device = 0;
+    rt::WideNode* nodes = nullptr;          // top-level tree
+    rt::InstanceRecord* instances = nullptr;
+    uint64_t nodeCount = 0;
+    uint32_t instanceCount = 0;
+    uint32_t depth = 0;
+    uint64_t blasNodes = 0, blasNodeBytes = 0, triangles = 0, triangleBytes = 0;
+    uint32_t blasDepth = 0;
+    std::vector<float> inverses;            // 12 floats per instance (host copy)
+    float buildMilliseconds = 0.0f;
+};

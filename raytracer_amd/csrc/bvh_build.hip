@@ -1,0 +1,801 @@
+// Acceleration-structure build for gfx950.
+//
+// Bottom level (replaces the OptiX GAS build, renderer.cpp:343-396), all on the
+// device: triangle bounds -> 63-bit Morton codes of the centroids -> stable radix
+// sort -> binary radix tree (Karras 2012) -> bottom-up bounds -> top-down
+// collapse into 8-wide nodes, one level per launch, where the child with the
+// largest surface area is opened first and subtrees of at most kMaxLeaf
+// triangles become leaf children -> 8-bit quantised child boxes.  Node and
+// triangle slots come from prefix sums over the level, so the layout is the
+// same on every run and every GPU.
+//
+// Top level (replaces the IAS build, renderer.cpp:398-434): built on the host
+// from the instances' transformed root boxes - instance counts are small - with
+// the same node format.
+#include "bvh.h"
+#include "radix_sort.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace rt {
+namespace {
+
+// ---- device helpers -------------------------------------------------------
+
+// Monotone map float -> uint32 so that integer atomics order floats.
+__device__ inline uint32_t orderedBits(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000U) ? ~b : (b | 0x80000000U);
+}
+__host__ __device__ inline float fromOrderedBits(uint32_t b) {
+    const uint32_t raw = (b & 0x80000000U) ? (b & 0x7fffffffU) : ~b;
+    float v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __uint_as_float(raw);
+#else
+    std::memcpy(&v, &raw, sizeof(v));
+#endif
+    return v;
+}
+
+struct Box4 {  // 32 bytes: lo.xyz, pad, hi.xyz, pad
+    float4 lo;
+    float4 hi;
+};
+
+__device__ inline float halfArea(const Box4& b) {
+    const float x = b.hi.x - b.lo.x, y = b.hi.y - b.lo.y, z = b.hi.z - b.lo.z;
+    return x * y + y * z + z * x;
+}
+
+__device__ inline Box4 merge(const Box4& a, const Box4& b) {
+    Box4 r;
+    r.lo = make_float4(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z), 0.0f);
+    r.hi = make_float4(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z), 0.0f);
+    return r;
+}
+
+__device__ inline float3 loadPosition(const uint8_t* vertices, uint32_t stride, uint32_t index) {
+    const float* p = reinterpret_cast<const float*>(vertices + static_cast<size_t>(index) * stride);
+    return make_float3(p[0], p[1], p[2]);
+}
+
+// ---- 1. triangle bounds + centroid extent ---------------------------------
+
+// centroidBounds: 6 ordered-bit words, lo.xyz then hi.xyz.
+__global__ __launch_bounds__(256) void triangleBoundsKernel(const uint8_t* vertices, uint32_t stride,
+                                                            const uint32_t* indices, uint32_t n, Box4* boxes,
+                                                            uint32_t* centroidBounds) {
+    __shared__ uint32_t block[6];
+    if (threadIdx.x < 3)
+        block[threadIdx.x] = 0xffffffffU;
+    else if (threadIdx.x < 6)
+        block[threadIdx.x] = 0U;
+    __syncthreads();
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float3 a = loadPosition(vertices, stride, indices[3 * i]);
+        const float3 b = loadPosition(vertices, stride, indices[3 * i + 1]);
+        const float3 c = loadPosition(vertices, stride, indices[3 * i + 2]);
+        Box4 box;
+        box.lo = make_float4(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z), 0.0f);
+        box.hi = make_float4(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z), 0.0f);
+        boxes[i] = box;
+        const float cx = 0.5f * (box.lo.x + box.hi.x), cy = 0.5f * (box.lo.y + box.hi.y),
+                    cz = 0.5f * (box.lo.z + box.hi.z);
+        atomicMin(&block[0], orderedBits(cx));
+        atomicMin(&block[1], orderedBits(cy));
+        atomicMin(&block[2], orderedBits(cz));
+        atomicMax(&block[3], orderedBits(cx));
+        atomicMax(&block[4], orderedBits(cy));
+        atomicMax(&block[5], orderedBits(cz));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicMin(&centroidBounds[threadIdx.x], block[threadIdx.x]);
+    else if (threadIdx.x < 6)
+        atomicMax(&centroidBounds[threadIdx.x], block[threadIdx.x]);
+}
+
+// ---- 2. Morton codes -------------------------------------------------------
+
+__device__ inline uint64_t spread21(uint64_t v) {
+    v &= 0x1fffffULL;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mortonKernel(const Box4* boxes, uint32_t n, const uint32_t* centroidBounds,
+                                                    uint64_t* keys) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const Box4 box = boxes[i];
+    float c[3] = {0.5f * (box.lo.x + box.hi.x), 0.5f * (box.lo.y + box.hi.y), 0.5f * (box.lo.z + box.hi.z)};
+    uint64_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fromOrderedBits(centroidBounds[a]);
+        const float hi = fromOrderedBits(centroidBounds[3 + a]);
+        const float extent = hi - lo;
+        float u = extent > 0.0f ? (c[a] - lo) / extent : 0.0f;
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        const uint32_t cell = static_cast<uint32_t>(u * 2097151.0f);
+        q[a] = cell > 2097151U ? 2097151U : cell;
+    }
+    keys[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+}
+
+// ---- 3. binary radix tree ---------------------------------------------------
+// Node ids: internal node i is id i (0 .. n-2), leaf k is id (n-1) + k.
+
+__device__ inline int commonPrefix(const uint64_t* keys, int n, int i, int j) {
+    if (j < 0 || j >= n)
+        return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b)
+        return 64 + __clz(static_cast<int>(static_cast<uint32_t>(i) ^ static_cast<uint32_t>(j)));
+    return __clzll(static_cast<long long>(a ^ b));
+}
+
+__global__ __launch_bounds__(256) void radixTreeKernel(const uint64_t* keys, uint32_t n, uint32_t* left,
+                                                       uint32_t* right, uint32_t* parent, uint32_t* first,
+                                                       uint32_t* last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = static_cast<int>(n);
+    if (i >= count - 1)
+        return;
+    const int d = commonPrefix(keys, count, i, i + 1) - commonPrefix(keys, count, i, i - 1) >= 0 ? 1 : -1;
+    const int deltaMin = commonPrefix(keys, count, i, i - d);
+    int lmax = 2;
+    while (commonPrefix(keys, count, i, i + lmax * d) > deltaMin)
+        lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (commonPrefix(keys, count, i, i + (l + t) * d) > deltaMin)
+            l += t;
+    const int j = i + l * d;
+    const int deltaNode = commonPrefix(keys, count, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) / 2;
+        if (commonPrefix(keys, count, i, i + (s + t) * d) > deltaNode)
+            s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const uint32_t l_id = lo == gamma ? (n - 1U) + gamma : static_cast<uint32_t>(gamma);
+    const uint32_t r_id = hi == gamma + 1 ? (n - 1U) + gamma + 1 : static_cast<uint32_t>(gamma + 1);
+    left[i] = l_id;
+    right[i] = r_id;
+    parent[l_id] = i;
+    parent[r_id] = i;
+    first[i] = lo;
+    last[i] = hi;
+    if (i == 0)
+        parent[0] = kNoHit;
+}
+
+// bounds[(n-1) + k] = box of the k-th triangle in sorted order
+__global__ __launch_bounds__(256) void leafBoundsKernel(const Box4* boxes, const uint32_t* order, uint32_t n,
+                                                        Box4* bounds) {
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < n)
+        bounds[(n - 1U) + k] = boxes[order[k]];
+}
+
+// Bottom-up: the second thread to reach a node merges its children.  The
+// fences order each thread's box stores before its arrival count and the
+// sibling's box loads after it, across CUs and XCDs.
+__global__ __launch_bounds__(256) void refitKernel(const uint32_t* left, const uint32_t* right,
+                                                   const uint32_t* parent, uint32_t n, Box4* bounds,
+                                                   uint32_t* arrivals) {
+    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n || n < 2)
+        return;
+    uint32_t node = parent[(n - 1U) + k];
+    while (node != kNoHit) {
+        __threadfence();
+        if (atomicAdd(&arrivals[node], 1U) == 0U)
+            return;
+        __threadfence();
+        const volatile Box4* vb = bounds;
+        Box4 a, b;
+        const uint32_t l = left[node], r = right[node];
+        a.lo = make_float4(vb[l].lo.x, vb[l].lo.y, vb[l].lo.z, 0.0f);
+        a.hi = make_float4(vb[l].hi.x, vb[l].hi.y, vb[l].hi.z, 0.0f);
+        b.lo = make_float4(vb[r].lo.x, vb[r].lo.y, vb[r].lo.z, 0.0f);
+        b.hi = make_float4(vb[r].hi.x, vb[r].hi.y, vb[r].hi.z, 0.0f);
+        bounds[node] = merge(a, b);
+        node = parent[node];
+    }
+}
+
+// ---- 4. collapse into wide nodes --------------------------------------------
+
+struct Child {
+    uint32_t id;     // radix-tree node id
+    uint32_t first;  // first sorted triangle
+    uint32_t count;  // triangles below
+    float area;
+};
+
+__device__ inline Child makeChild(uint32_t id, uint32_t n, const uint32_t* first, const uint32_t* last,
+                                  const Box4* bounds) {
+    Child c;
+    c.id = id;
+    if (id >= n - 1U) {
+        c.first = id - (n - 1U);
+        c.count = 1;
+    } else {
+        c.first = first[id];
+        c.count = last[id] - first[id] + 1U;
+    }
+    c.area = halfArea(bounds[id]);
+    return c;
+}
+
+// Opens the children of radix-tree node `root` until eight are held or none can
+// be opened; children stay in sorted-triangle order.
+__device__ inline int gatherChildren(uint32_t root, uint32_t n, const uint32_t* left, const uint32_t* right,
+                                     const uint32_t* first, const uint32_t* last, const Box4* bounds,
+                                     Child* children) {
+    int count;
+    if (root >= n - 1U || last[root] - first[root] + 1U <= static_cast<uint32_t>(kMaxLeaf)) {
+        // the whole tree is one leaf (only the root entry can get here)
+        children[0] = makeChild(root, n, first, last, bounds);
+        return 1;
+    }
+    children[0] = makeChild(left[root], n, first, last, bounds);
+    children[1] = makeChild(right[root], n, first, last, bounds);
+    count = 2;
+    while (count < kWide) {
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < count; ++k)
+            if (children[k].count > static_cast<uint32_t>(kMaxLeaf) && children[k].area > best) {
+                best = children[k].area;
+                pick = k;
+            }
+        if (pick < 0)
+            break;
+        const uint32_t id = children[pick].id;
+        for (int k = count; k > pick + 1; --k)
+            children[k] = children[k - 1];
+        children[pick] = makeChild(left[id], n, first, last, bounds);
+        children[pick + 1] = makeChild(right[id], n, first, last, bounds);
+        ++count;
+    }
+    return count;
+}
+
+// Pass A over one level: how many node and triangle slots each entry needs.
+__global__ __launch_bounds__(128) void collapseCountKernel(const uint32_t* frontier, uint32_t entries, uint32_t n,
+                                                           const uint32_t* left, const uint32_t* right,
+                                                           const uint32_t* first, const uint32_t* last,
+                                                           const Box4* bounds, uint32_t* nodeCounts,
+                                                           uint32_t* triCounts) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > entries)
+        return;
+    if (e == entries) {  // sentinel so the exclusive scan yields the totals
+        nodeCounts[e] = 0;
+        triCounts[e] = 0;
+        return;
+    }
+    Child children[kWide];
+    const int count = gatherChildren(frontier[e], n, left, right, first, last, bounds, children);
+    uint32_t nodes = 0, tris = 0;
+    for (int k = 0; k < count; ++k) {
+        if (children[k].count > static_cast<uint32_t>(kMaxLeaf))
+            ++nodes;
+        else
+            tris += children[k].count;
+    }
+    nodeCounts[e] = nodes;
+    triCounts[e] = tris;
+}
+
+__device__ inline float scaleOf(uint8_t e) {
+    return __uint_as_float(static_cast<uint32_t>(e) << 23);
+}
+
+// Grows the box by a few ulps of its coordinates: the traversal's slab test
+// then never rejects a triangle its own intersection test accepts.
+__device__ inline void padBox(Box4& b) {
+    float* lo = &b.lo.x;
+    float* hi = &b.hi.x;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float m = fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), hi[a] - lo[a]);
+        const float pad = fmaxf(m * 0x1p-18f, 1e-30f);
+        lo[a] -= pad;
+        hi[a] += pad;
+    }
+}
+
+// Pass B: writes the wide node of each entry, its leaf triangles and the next
+// level's entries.  levelNodeBase = index of this level's first node;
+// nextNodeBase = index the next level starts at; triBase likewise.
+__global__ __launch_bounds__(128) void collapseEmitKernel(
+    const uint32_t* frontier, uint32_t entries, uint32_t n, const uint32_t* left, const uint32_t* right,
+    const uint32_t* first, const uint32_t* last, const Box4* bounds, const uint32_t* nodeOffsets,
+    const uint32_t* triOffsets, uint32_t levelNodeBase, uint32_t nextNodeBase, uint32_t triBase,
+    const uint32_t* order, const uint8_t* vertices, uint32_t stride, const uint32_t* indices, WideNode* nodes,
+    PackedTriangle* triangles, uint32_t* nextFrontier, Box4* rootBox) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries)
+        return;
+    Child children[kWide];
+    const int count = gatherChildren(frontier[e], n, left, right, first, last, bounds, children);
+
+    Box4 boxes[kWide];
+    Box4 all;
+    for (int k = 0; k < count; ++k) {
+        boxes[k] = bounds[children[k].id];
+        padBox(boxes[k]);
+        all = k == 0 ? boxes[0] : merge(all, boxes[k]);
+    }
+    if (rootBox && e == 0)
+        *rootBox = all;
+
+    WideNode node;
+    std::memset(&node, 0, sizeof(node));
+    const float lo[3] = {all.lo.x, all.lo.y, all.lo.z};
+    const float hi[3] = {all.hi.x, all.hi.y, all.hi.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        node.origin[a] = lo[a];
+        // smallest power of two with 255 steps covering the extent
+        int ex;
+        frexpf((hi[a] - lo[a]) / 255.0f, &ex);
+        int biased = ex + 127;
+        biased = biased < 1 ? 1 : (biased > 254 ? 254 : biased);
+        while (biased < 254 && lo[a] + 255.0f * scaleOf(static_cast<uint8_t>(biased)) < hi[a])
+            ++biased;
+        node.exp[a] = static_cast<uint8_t>(biased);
+    }
+    const uint32_t childBase = nextNodeBase + nodeOffsets[e];
+    const uint32_t primBase = triBase + triOffsets[e];
+    node.childBase = childBase;
+    node.primBase = primBase;
+    uint32_t nodeSlot = 0, triSlot = 0;
+    for (int k = 0; k < count; ++k) {
+        const float* clo = &boxes[k].lo.x;
+        const float* chi = &boxes[k].hi.x;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float scale = scaleOf(node.exp[a]);
+            float ql = floorf((clo[a] - lo[a]) / scale);
+            ql = fminf(fmaxf(ql, 0.0f), 255.0f);
+            while (ql > 0.0f && lo[a] + ql * scale > clo[a])
+                ql -= 1.0f;
+            float qh = ceilf((chi[a] - lo[a]) / scale);
+            qh = fminf(fmaxf(qh, 0.0f), 255.0f);
+            while (qh < 255.0f && lo[a] + qh * scale < chi[a])
+                qh += 1.0f;
+            node.qlo[a][k] = static_cast<uint8_t>(ql);
+            node.qhi[a][k] = static_cast<uint8_t>(qh);
+        }
+        if (children[k].count > static_cast<uint32_t>(kMaxLeaf)) {
+            node.imask |= static_cast<uint8_t>(1U << k);
+            node.meta[k] = static_cast<uint8_t>(nodeSlot);
+            nextFrontier[nodeOffsets[e] + nodeSlot] = children[k].id;
+            ++nodeSlot;
+        } else {
+            node.meta[k] = static_cast<uint8_t>(children[k].count << 5 | triSlot);
+            for (uint32_t t = 0; t < children[k].count; ++t) {
+                const uint32_t prim = order[children[k].first + t];
+                const float3 a = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim)]);
+                const float3 b = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 1]);
+                const float3 c = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 2]);
+                PackedTriangle tri;
+                tri.v0[0] = a.x; tri.v0[1] = a.y; tri.v0[2] = a.z; tri.primitive = prim;
+                tri.v1[0] = b.x; tri.v1[1] = b.y; tri.v1[2] = b.z; tri.pad1 = 0;
+                tri.v2[0] = c.x; tri.v2[1] = c.y; tri.v2[2] = c.z; tri.pad2 = 0;
+                triangles[primBase + triSlot + t] = tri;
+            }
+            triSlot += children[k].count;
+        }
+    }
+    nodes[levelNodeBase + e] = node;
+}
+
+// ---- host side --------------------------------------------------------------
+
+struct DeviceBuffer {
+    void* data = nullptr;
+    ~DeviceBuffer() {
+        if (data)
+            (void)hipFree(data);
+    }
+    rt_status allocate(size_t bytes) {
+        RT_HIP(hipMalloc(&data, bytes ? bytes : 1));
+        return RT_SUCCESS;
+    }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(data);
+    }
+};
+
+rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
+                    hipStream_t stream, rt_blas* blas) {
+    (void)vertexCount;
+    hipEvent_t start, stop;
+    RT_HIP(hipEventCreate(&start));
+    RT_HIP(hipEventCreate(&stop));
+    RT_HIP(hipEventRecord(start, stream));
+
+    const uint32_t ids = 2U * n - 1U;
+    const size_t maxNodes = static_cast<size_t>(0.35 * n) + 16;
+    DeviceBuffer boxes, cbounds, keysA, keysB, idxA, idxB, table, partials, left, right, parent, first, last, bounds,
+        arrivals, frontierA, frontierB, nodeCounts, triCounts, tempNodes, rootBox;
+    RT_TRY(boxes.allocate(sizeof(Box4) * n));
+    RT_TRY(cbounds.allocate(sizeof(uint32_t) * 6));
+    RT_TRY(keysA.allocate(sizeof(uint64_t) * n));
+    RT_TRY(keysB.allocate(sizeof(uint64_t) * n));
+    RT_TRY(idxA.allocate(sizeof(uint32_t) * n));
+    RT_TRY(idxB.allocate(sizeof(uint32_t) * n));
+    RT_TRY(table.allocate(sizeof(uint32_t) * sortTableEntries(n)));
+    const size_t scanEntries = std::max(scanScratchEntries(sortTableEntries(n)), scanScratchEntries(maxNodes + 1));
+    RT_TRY(partials.allocate(sizeof(uint32_t) * scanEntries));
+    RT_TRY(left.allocate(sizeof(uint32_t) * n));
+    RT_TRY(right.allocate(sizeof(uint32_t) * n));
+    RT_TRY(parent.allocate(sizeof(uint32_t) * ids));
+    RT_TRY(first.allocate(sizeof(uint32_t) * n));
+    RT_TRY(last.allocate(sizeof(uint32_t) * n));
+    RT_TRY(bounds.allocate(sizeof(Box4) * ids));
+    RT_TRY(arrivals.allocate(sizeof(uint32_t) * n));
+    RT_TRY(frontierA.allocate(sizeof(uint32_t) * maxNodes));
+    RT_TRY(frontierB.allocate(sizeof(uint32_t) * maxNodes));
+    RT_TRY(nodeCounts.allocate(sizeof(uint32_t) * (maxNodes + 1)));
+    RT_TRY(triCounts.allocate(sizeof(uint32_t) * (maxNodes + 1)));
+    RT_TRY(tempNodes.allocate(sizeof(WideNode) * maxNodes));
+    RT_TRY(rootBox.allocate(sizeof(Box4)));
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&blas->triangles), sizeof(PackedTriangle) * n));
+
+    const uint32_t initBounds[6] = {0xffffffffU, 0xffffffffU, 0xffffffffU, 0U, 0U, 0U};
+    RT_HIP(hipMemcpyAsync(cbounds.data, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream));
+    const auto* vbytes = static_cast<const uint8_t*>(vertices);
+    const unsigned blocks = divUp(n, 256);
+    hipLaunchKernelGGL(triangleBoundsKernel, dim3(blocks), dim3(256), 0, stream, vbytes, stride, indices, n,
+                       boxes.as<Box4>(), cbounds.as<uint32_t>());
+    hipLaunchKernelGGL(mortonKernel, dim3(blocks), dim3(256), 0, stream, boxes.as<Box4>(), n, cbounds.as<uint32_t>(),
+                       keysA.as<uint64_t>());
+    RT_HIP(hipGetLastError());
+    uint64_t* const keys[2] = {keysA.as<uint64_t>(), keysB.as<uint64_t>()};
+    uint32_t* const idx[2] = {idxA.as<uint32_t>(), idxB.as<uint32_t>()};
+    int result = 0;
+    RT_TRY(radixSortPairs<uint64_t>(keys, idx, n, 63, table.as<uint32_t>(), partials.as<uint32_t>(), stream, &result));
+    const uint64_t* sortedKeys = keys[result];
+    const uint32_t* order = idx[result];
+
+    hipLaunchKernelGGL(leafBoundsKernel, dim3(blocks), dim3(256), 0, stream, boxes.as<Box4>(), order, n,
+                       bounds.as<Box4>());
+    if (n >= 2) {
+        hipLaunchKernelGGL(radixTreeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, sortedKeys, n,
+                           left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), first.as<uint32_t>(),
+                           last.as<uint32_t>());
+        RT_HIP(hipMemsetAsync(arrivals.data, 0, sizeof(uint32_t) * n, stream));
+        hipLaunchKernelGGL(refitKernel, dim3(blocks), dim3(256), 0, stream, left.as<uint32_t>(), right.as<uint32_t>(),
+                           parent.as<uint32_t>(), n, bounds.as<Box4>(), arrivals.as<uint32_t>());
+    }
+    RT_HIP(hipGetLastError());
+
+    // top-down collapse, one level per iteration
+    uint32_t* frontier = frontierA.as<uint32_t>();
+    uint32_t* nextFrontier = frontierB.as<uint32_t>();
+    const uint32_t rootId = 0;  // internal node 0, or leaf 0 when n == 1 (id n-1 = 0)
+    RT_HIP(hipMemcpyAsync(frontier, &rootId, sizeof(rootId), hipMemcpyHostToDevice, stream));
+    uint32_t entries = 1, levelNodeBase = 0, triBase = 0, depth = 0;
+    while (entries > 0) {
+        if (static_cast<size_t>(levelNodeBase) + entries > maxNodes)
+            return failInvalid("wide-node estimate exceeded");
+        hipLaunchKernelGGL(collapseCountKernel, dim3(divUp(entries + 1, 128)), dim3(128), 0, stream, frontier, entries,
+                           n, left.as<uint32_t>(), right.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(),
+                           bounds.as<Box4>(), nodeCounts.as<uint32_t>(), triCounts.as<uint32_t>());
+        RT_TRY(exclusiveScanU32(nodeCounts.as<uint32_t>(), nodeCounts.as<uint32_t>(), entries + 1,
+                                partials.as<uint32_t>(), stream));
+        RT_TRY(exclusiveScanU32(triCounts.as<uint32_t>(), triCounts.as<uint32_t>(), entries + 1,
+                                partials.as<uint32_t>(), stream));
+        uint32_t totals[2] = {0, 0};
+        RT_HIP(hipMemcpyAsync(&totals[0], nodeCounts.as<uint32_t>() + entries, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipMemcpyAsync(&totals[1], triCounts.as<uint32_t>() + entries, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+        const uint32_t nextNodeBase = levelNodeBase + entries;
+        if (static_cast<size_t>(nextNodeBase) + totals[0] > maxNodes || static_cast<uint64_t>(triBase) + totals[1] > n)
+            return failInvalid("wide-node estimate exceeded");
+        hipLaunchKernelGGL(collapseEmitKernel, dim3(divUp(entries, 128)), dim3(128), 0, stream, frontier, entries, n,
+                           left.as<uint32_t>(), right.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(),
+                           bounds.as<Box4>(), nodeCounts.as<uint32_t>(), triCounts.as<uint32_t>(), levelNodeBase,
+                           nextNodeBase, triBase, order, vbytes, stride, indices, tempNodes.as<WideNode>(),
+                           blas->triangles, nextFrontier, depth == 0 ? rootBox.as<Box4>() : nullptr);
+        RT_HIP(hipGetLastError());
+        levelNodeBase = nextNodeBase;
+        triBase += totals[1];
+        entries = totals[0];
+        std::swap(frontier, nextFrontier);
+        ++depth;
+    }
+    if (triBase != n)
+        return failInvalid("collapse lost triangles");
+
+    blas->nodeCount = levelNodeBase;
+    blas->triangleCount = n;
+    blas->depth = depth;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&blas->nodes), sizeof(WideNode) * blas->nodeCount));
+    RT_HIP(hipMemcpyAsync(blas->nodes, tempNodes.data, sizeof(WideNode) * blas->nodeCount, hipMemcpyDeviceToDevice,
+                          stream));
+    Box4 root;
+    RT_HIP(hipMemcpyAsync(&root, rootBox.data, sizeof(root), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipEventRecord(stop, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    RT_HIP(hipEventElapsedTime(&blas->buildMilliseconds, start, stop));
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    blas->bounds = {{root.lo.x, root.lo.y, root.lo.z}, {root.hi.x, root.hi.y, root.hi.z}};
+    return RT_SUCCESS;
+}
+
+// ---- top level (host) ---------------------------------------------------------
+
+// Inverse of the affine 3x4 in binary64, each entry rounded once to binary32.
+void invertAffine(const float* m, float* out) {
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
+    const double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+    const double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
+    const double det = a * c00 + b * c10 + c * c20;
+    const double r = 1.0 / det;
+    const double inv[9] = {c00 * r, c01 * r, c02 * r, c10 * r, c11 * r, c12 * r, c20 * r, c21 * r, c22 * r};
+    const double tx = m[3], ty = m[7], tz = m[11];
+    for (int row = 0; row < 3; ++row) {
+        out[row * 4 + 0] = static_cast<float>(inv[row * 3 + 0]);
+        out[row * 4 + 1] = static_cast<float>(inv[row * 3 + 1]);
+        out[row * 4 + 2] = static_cast<float>(inv[row * 3 + 2]);
+        out[row * 4 + 3] =
+            static_cast<float>(-(inv[row * 3 + 0] * tx + inv[row * 3 + 1] * ty + inv[row * 3 + 2] * tz));
+    }
+}
+
+Aabb emptyBox() {
+    return {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+}
+
+void growBox(Aabb& b, const Aabb& o) {
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = std::min(b.lo[a], o.lo[a]);
+        b.hi[a] = std::max(b.hi[a], o.hi[a]);
+    }
+}
+
+// World-space box of an instance: the eight corners of the bottom-level root
+// box through the object->world transform, then a margin for the rounding of
+// the inverse transform the rays go through.
+Aabb instanceBox(const float* m, const Aabb& object) {
+    Aabb box = emptyBox();
+    for (int corner = 0; corner < 8; ++corner) {
+        const double x = corner & 1 ? object.hi[0] : object.lo[0];
+        const double y = corner & 2 ? object.hi[1] : object.lo[1];
+        const double z = corner & 4 ? object.hi[2] : object.lo[2];
+        for (int a = 0; a < 3; ++a) {
+            const double v = m[a * 4] * x + m[a * 4 + 1] * y + m[a * 4 + 2] * z + m[a * 4 + 3];
+            box.lo[a] = std::min(box.lo[a], static_cast<float>(std::nextafter(static_cast<float>(v), -INFINITY)));
+            box.hi[a] = std::max(box.hi[a], static_cast<float>(std::nextafter(static_cast<float>(v), INFINITY)));
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        const float m2 = std::max(std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a])), box.hi[a] - box.lo[a]);
+        const float pad = std::max(m2 * 0x1p-16f, 1e-30f);
+        box.lo[a] -= pad;
+        box.hi[a] += pad;
+    }
+    return box;
+}
+
+float scaleOfHost(uint8_t e) {
+    const uint32_t bits = static_cast<uint32_t>(e) << 23;
+    float v;
+    std::memcpy(&v, &bits, sizeof(v));
+    return v;
+}
+
+// Median-split tree over instance boxes written straight into wide nodes:
+// every node takes up to eight children by repeatedly splitting the group with
+// the largest box; a group of one instance is a leaf child.
+struct TopBuilder {
+    const std::vector<Aabb>& boxes;
+    std::vector<uint32_t> order;      // instance permutation, leaf items refer to it
+    std::vector<WideNode> nodes;
+    uint32_t depth = 0;
+
+    struct Group {
+        uint32_t first, count;
+        Aabb box;
+    };
+
+    explicit TopBuilder(const std::vector<Aabb>& b) : boxes(b), order(b.size()) {
+        for (uint32_t i = 0; i < order.size(); ++i)
+            order[i] = i;
+    }
+
+    Aabb boxOf(uint32_t first, uint32_t count) const {
+        Aabb box = emptyBox();
+        for (uint32_t i = first; i < first + count; ++i)
+            growBox(box, boxes[order[i]]);
+        return box;
+    }
+
+    static float area(const Aabb& b) {
+        const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    }
+
+    void split(const Group& g, Group& l, Group& r) {
+        Aabb centers = emptyBox();
+        for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+            const Aabb& b = boxes[order[i]];
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (b.lo[a] + b.hi[a]);
+                centers.lo[a] = std::min(centers.lo[a], c);
+                centers.hi[a] = std::max(centers.hi[a], c);
+            }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (centers.hi[a] - centers.lo[a] > centers.hi[axis] - centers.lo[axis])
+                axis = a;
+        const uint32_t mid = g.first + g.count / 2;
+        std::nth_element(order.begin() + g.first, order.begin() + mid, order.begin() + g.first + g.count,
+                         [&](uint32_t x, uint32_t y) {
+                             const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
+                             const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+                             return cx < cy || (cx == cy && x < y);
+                         });
+        l = {g.first, mid - g.first, boxOf(g.first, mid - g.first)};
+        r = {mid, g.first + g.count - mid, boxOf(mid, g.first + g.count - mid)};
+    }
+
+    // Builds the node for `group` at index `self`; children nodes are appended.
+    void build(uint32_t self, const Group& group, uint32_t level) {
+        depth = std::max(depth, level + 1);
+        std::vector<Group> groups{group};
+        if (group.count > 1) {
+            while (groups.size() < static_cast<size_t>(kWide)) {
+                int pick = -1;
+                float best = -1.0f;
+                for (size_t k = 0; k < groups.size(); ++k)
+                    if (groups[k].count > 1 && area(groups[k].box) > best) {
+                        best = area(groups[k].box);
+                        pick = static_cast<int>(k);
+                    }
+                if (pick < 0)
+                    break;
+                Group l, r;
+                split(groups[pick], l, r);
+                groups[pick] = l;
+                groups.insert(groups.begin() + pick + 1, r);
+            }
+        }
+        Aabb all = emptyBox();
+        for (const auto& g : groups)
+            growBox(all, g.box);
+        WideNode node;
+        std::memset(&node, 0, sizeof(node));
+        for (int a = 0; a < 3; ++a) {
+            node.origin[a] = all.lo[a];
+            int ex;
+            std::frexp((all.hi[a] - all.lo[a]) / 255.0f, &ex);
+            int biased = std::min(std::max(ex + 127, 1), 254);
+            while (biased < 254 && all.lo[a] + 255.0f * scaleOfHost(static_cast<uint8_t>(biased)) < all.hi[a])
+                ++biased;
+            node.exp[a] = static_cast<uint8_t>(biased);
+        }
+        uint32_t internal = 0;
+        for (const auto& g : groups)
+            internal += g.count > 1;
+        const uint32_t childBase = static_cast<uint32_t>(nodes.size());
+        nodes.resize(nodes.size() + internal);
+        node.childBase = childBase;
+        // leaf items of one node must be contiguous in `order`: groups are in
+        // range order and cover [group.first, group.first + group.count), so
+        // items are addressed relative to the node's first instance
+        node.primBase = group.first;
+        uint32_t slot = 0;
+        std::vector<std::pair<uint32_t, Group>> pending;
+        for (size_t k = 0; k < groups.size(); ++k) {
+            const Group& g = groups[k];
+            for (int a = 0; a < 3; ++a) {
+                const float scale = scaleOfHost(node.exp[a]);
+                float ql = std::floor((g.box.lo[a] - all.lo[a]) / scale);
+                ql = std::min(std::max(ql, 0.0f), 255.0f);
+                while (ql > 0.0f && all.lo[a] + ql * scale > g.box.lo[a])
+                    ql -= 1.0f;
+                float qh = std::ceil((g.box.hi[a] - all.lo[a]) / scale);
+                qh = std::min(std::max(qh, 0.0f), 255.0f);
+                while (qh < 255.0f && all.lo[a] + qh * scale < g.box.hi[a])
+                    qh += 1.0f;
+                node.qlo[a][k] = static_cast<uint8_t>(ql);
+                node.qhi[a][k] = static_cast<uint8_t>(qh);
+            }
+            if (g.count > 1) {
+                node.imask |= static_cast<uint8_t>(1U << k);
+                node.meta[k] = static_cast<uint8_t>(slot);
+                pending.emplace_back(childBase + slot, g);
+                ++slot;
+            } else {
+                node.meta[k] = static_cast<uint8_t>(1U << 5 | 0U);
+                // single instances are addressed through a per-child base: see below
+            }
+        }
+        nodes[self] = node;
+        for (auto& p : pending)
+            build(p.first, p.second, level + 1);
+    }
+};
+
+}  // namespace
+}  // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+rt_status rt_blas_build(const void* vertices, uint32_t vertexCount, uint32_t vertexStride, const uint32_t* indices,
+                        uint32_t triangleCount, void* stream, rt_blas** out) {
+    if (!out)
+        return failInvalid("out is null");
+    *out = nullptr;
+    if (!vertices || !indices || triangleCount == 0 || vertexCount == 0)
+        return failInvalid("empty geometry");
+    if (vertexStride < 12 || vertexStride % 4 != 0)
+        return failInvalid("vertex stride must be a multiple of 4 and at least 12");
+    if (triangleCount > (1U << 28) - 1U)
+        return failInvalid("too many triangles");
+    auto* blas = new rt_blas();
+    RT_HIP(hipGetDevice(&blas->device));
+    const rt_status status = buildBlas(vertices, vertexCount, vertexStride, indices, triangleCount,
+                                       static_cast<hipStream_t>(stream), blas);
+    if (status != RT_SUCCESS) {
+        rt_blas_destroy(blas);
+        return status;
+    }
+    *out = blas;
+    return RT_SUCCESS;
+}
+
+void rt_blas_destroy(rt_blas* blas) {
+    if (!blas)
+        return;
+    if (blas->nodes)
+        (void)hipFree(blas->nodes);
+    if (blas->triangles)
+        (void)hipFree(blas->triangles);
+    delete blas;
+}
+
+rt_status rt_blas_stats(const rt_blas* blas, rt_bvh_stats* out) {
+    if (!blas || !out)
+        return failInvalid("null pointer");
+    out->nodeCount = blas->nodeCount;
+    out->nodeBytes = blas->nodeCount * sizeof(WideNode);
+    out->triangleCount = blas->triangleCount;
+    out->triangleBytes = blas->triangleCount * sizeof(PackedTriangle);
+    out->instanceCount = 0;
+    out->maxDepth = blas->depth;
+    out->buildMilliseconds = blas->buildMilliseconds;
+    return RT_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Photon hash grid for gfx950: bucket keys, a stable radix sort of (key, index)
+// pairs, bucket offsets by binary search over the sorted keys, a payload
+// reorder staged through LDS, and the radius gather.
+//
+// Replaces src/photon_grid.cu:17-83 (count / scan / scatter with global
+// atomics) and the gather loop of src/device.cu:722-766 of the reference.  The
+// sort keeps photons of one bucket in input order, so the grid and every gather
+// sum are reproducible.
+#include "common.h"
+#include "radix_sort.h"
+
+#include <mutex>
+
+namespace rt {
+namespace {
+
+// float -> int32, saturating, NaN -> 0 (the conversion the reference's
+// static_cast<int>(floorf(..)) performs on the GPU; spelled out because an
+// out-of-range cast is undefined for the compiler).
+__device__ inline int toInt(float v) {
+    if (v != v)
+        return 0;
+    if (v >= 2147483648.0f)
+        return 2147483647;
+    if (v <= -2147483648.0f)
+        return -2147483647 - 1;
+    return static_cast<int>(v);
+}
+
+// src/photon_hash.cuh:10-24.  The division is the correctly rounded IEEE one.
+__device__ inline uint32_t bucketOfCell(int x, int y, int z, uint32_t bucketCount) {
+    const uint32_t hash = static_cast<uint32_t>(x) * 73856093U ^ static_cast<uint32_t>(y) * 19349663U ^
+                          static_cast<uint32_t>(z) * 83492791U;
+    return hash & (bucketCount - 1U);
+}
+
+__device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float cellSize, uint32_t bucketCount) {
+    return bucketOfCell(toInt(floorf(px / cellSize)), toInt(floorf(py / cellSize)), toInt(floorf(pz / cellSize)),
+                        bucketCount);
+}
+
+// positions: float3 at `stride` floats.
+__global__ __launch_bounds__(256) void photonKeysKernel(const float* positions, uint32_t stride, uint32_t n,
+                                                        float cellSize, uint32_t bucketCount, uint32_t* keys) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const float* p = positions + i * stride;
+        keys[i] = bucketOfPosition(p[0], p[1], p[2], cellSize, bucketCount);
+    }
+}
+
+// offsets[b] = first sorted position whose key is >= b, for b in [0, bucketCount].
+// Neighbouring buckets search neighbouring key ranges, so a wave's probes share
+// cache lines.
+__global__ __launch_bounds__(256) void photonOffsetsKernel(const uint32_t* sortedKeys, uint32_t n,
+                                                           uint32_t bucketCount, uint32_t* offsets) {
+    const size_t b = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b > bucketCount)
+        return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2U;
+        if (sortedKeys[mid] < b)
+            lo = mid + 1U;
+        else
+            hi = mid;
+    }
+    offsets[b] = lo;
+}
+
+// sorted[i] = photons[order[i]].  A workgroup gathers 256 photons (36 bytes
+// each, scattered) into LDS and streams the 9216 contiguous bytes out as
+// 16-byte stores.
+__global__ __launch_bounds__(256) void photonReorderKernel(const rt_photon* photons, const uint32_t* order,
+                                                           uint32_t n, rt_photon* sorted) {
+    __shared__ float4 stage[256 * 9 / 4];  // 9216 bytes
+    float* flat = reinterpret_cast<float*>(stage);
+    const size_t base = static_cast<size_t>(blockIdx.x) * 256;
+    const size_t i = base + threadIdx.x;
+    if (i < n) {
+        const float* src = reinterpret_cast<const float*>(photons + order[i]);
+        float* dst = flat + threadIdx.x * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            dst[k] = src[k];
+    }
+    __syncthreads();
+    const uint32_t count = static_cast<uint32_t>(min(static_cast<size_t>(256), n - base));
+    float* out = reinterpret_cast<float*>(sorted + base);
+    if (count == 256) {
+        // workgroup base offset 256 * 36 * blockIdx is a multiple of 16 bytes
+        float4* out4 = reinterpret_cast<float4*>(out);
+        for (uint32_t k = threadIdx.x; k < 256 * 9 / 4; k += 256)
+            out4[k] = stage[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < count * 9; k += 256)
+            out[k] = flat[k];
+    }
+}
+
+// One query per lane, the loop of src/device.cu:729-762 in its own order, so
+// the float sums match a scalar evaluation bit for bit.
+__global__ __launch_bounds__(256) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
+                                                          uint32_t bucketCount, float radius, const float* qpos,
+                                                          const float* qnormal, uint32_t n, float* flux) {
+    const size_t q = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= n)
+        return;
+    const float hx = qpos[3 * q], hy = qpos[3 * q + 1], hz = qpos[3 * q + 2];
+    const float nx = qnormal[3 * q], ny = qnormal[3 * q + 1], nz = qnormal[3 * q + 2];
+    const int cx = toInt(floorf(hx / radius));
+    const int cy = toInt(floorf(hy / radius));
+    const int cz = toInt(floorf(hz / radius));
+    const float radiusSquared = radius * radius;
+    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+    // The 27 buckets first (two cells can share a bucket: keep the first), then
+    // their ranges, so the range loads are independent of the photon loop.
+    uint32_t visited[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        visited[c] = bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
+                                  static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
+                                  static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+    }
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        bool seen = false;
+#pragma unroll
+        for (int p = 0; p < c; ++p)
+            seen |= visited[p] == visited[c];
+        if (seen)
+            continue;
+        const uint32_t begin = cellStart[visited[c]];
+        const uint32_t end = cellStart[visited[c] + 1U];
+        for (uint32_t index = begin; index < end; ++index) {
+            const float* p = reinterpret_cast<const float*>(sorted + index);
+            const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
+            const float distanceSquared = ox * ox + oy * oy + oz * oz;
+            const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
+            if (distanceSquared >= radiusSquared || cosine < 0.7f)
+                continue;
+            const float weight = 1.0f - distanceSquared / radiusSquared;
+            fx = fx + p[3] * weight;
+            fy = fy + p[4] * weight;
+            fz = fz + p[5] * weight;
+        }
+    }
+    flux[3 * q] = fx;
+    flux[3 * q + 1] = fy;
+    flux[3 * q + 2] = fz;
+}
+
+struct GridScratch {
+    uint32_t* keys[2];
+    uint32_t* idx[2];
+    uint32_t* table;
+    uint32_t* partials;
+};
+
+size_t scratchBytes(uint32_t maxCount, uint32_t bucketCount) {
+    (void)bucketCount;
+    const size_t n = alignUp(static_cast<size_t>(maxCount) * sizeof(uint32_t), 256);
+    const size_t table = alignUp(sortTableEntries(maxCount) * sizeof(uint32_t), 256);
+    const size_t partials = alignUp(scanScratchEntries(sortTableEntries(maxCount)) * sizeof(uint32_t), 256);
+    return 4 * n + table + partials + 256;
+}
+
+GridScratch carve(void* scratch, uint32_t maxCount) {
+    auto base = reinterpret_cast<uintptr_t>(scratch);
+    base = (base + 255) / 256 * 256;
+    const size_t n = alignUp(static_cast<size_t>(maxCount) * sizeof(uint32_t), 256);
+    const size_t table = alignUp(sortTableEntries(maxCount) * sizeof(uint32_t), 256);
+    GridScratch s;
+    s.keys[0] = reinterpret_cast<uint32_t*>(base);
+    s.keys[1] = reinterpret_cast<uint32_t*>(base + n);
+    s.idx[0] = reinterpret_cast<uint32_t*>(base + 2 * n);
+    s.idx[1] = reinterpret_cast<uint32_t*>(base + 3 * n);
+    s.table = reinterpret_cast<uint32_t*>(base + 4 * n);
+    s.partials = reinterpret_cast<uint32_t*>(base + 4 * n + table);
+    return s;
+}
+
+// Workspace the library owns, per device, grown on demand, for callers whose
+// scratch buffer is smaller than the sort needs.
+struct Workspace {
+    void* data = nullptr;
+    size_t bytes = 0;
+};
+std::mutex workspaceMutex;
+Workspace workspaces[64];
+
+rt_status ownedWorkspace(size_t bytes, void** out) {
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64)
+        return failInvalid("device index");
+    std::lock_guard<std::mutex> lock(workspaceMutex);
+    Workspace& w = workspaces[device];
+    if (w.bytes < bytes) {
+        if (w.data) {
+            RT_HIP(hipDeviceSynchronize());
+            RT_HIP(hipFree(w.data));
+            w.data = nullptr;
+            w.bytes = 0;
+        }
+        RT_HIP(hipMalloc(&w.data, bytes));
+        w.bytes = bytes;
+    }
+    *out = w.data;
+    return RT_SUCCESS;
+}
+
+int log2Exact(uint32_t v) {
+    int bits = 0;
+    while ((1U << bits) < v)
+        ++bits;
+    return bits;
+}
+
+rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount, uint32_t* counts,
+                    uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted, hipStream_t stream) {
+    (void)counts;  // clobbered upstream; nothing here needs it
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return failInvalid("bucketCount must be a power of two");
+    if (!offsets)
+        return failInvalid("offsets is null");
+    if (count == 0) {
+        RT_HIP(hipMemsetAsync(offsets, 0, (static_cast<size_t>(bucketCount) + 1U) * sizeof(uint32_t), stream));
+        return RT_SUCCESS;
+    }
+    if (!photons || !sorted)
+        return failInvalid("photons / sorted is null");
+    const size_t needed = scratchBytes(count, bucketCount);
+    void* workspace = scan;
+    if (!scan || scanBytes < needed)
+        RT_TRY(ownedWorkspace(needed, &workspace));
+    const GridScratch s = carve(workspace, count);
+
+    hipLaunchKernelGGL(photonKeysKernel, dim3(stridedGrid(count, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float*>(photons), 9U, count, cellSize, bucketCount, s.keys[0]);
+    RT_HIP(hipGetLastError());
+    int result = 0;
+    const int bits = log2Exact(bucketCount) > 0 ? log2Exact(bucketCount) : 1;
+    RT_TRY(radixSortPairs<uint32_t>(s.keys, s.idx, count, bits, s.table, s.partials, stream, &result));
+    hipLaunchKernelGGL(photonOffsetsKernel, dim3(divUp(static_cast<size_t>(bucketCount) + 1U, 256)), dim3(256), 0,
+                       stream, s.keys[result], count, bucketCount, offsets);
+    hipLaunchKernelGGL(photonReorderKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, photons, s.idx[result],
+                       count, sorted);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+}  // namespace
+}  // namespace rt
+
+extern "C" {
+
+size_t rt_photon_grid_scratch_bytes(uint32_t maxCount, uint32_t bucketCount) {
+    return rt::scratchBytes(maxCount, bucketCount);
+}
+
+size_t rt_photon_scan_storage(uint32_t bucketCount) {
+    const uint64_t capacity = 2ULL * bucketCount;
+    return rt::scratchBytes(static_cast<uint32_t>(capacity > 0xffffffffULL ? 0xffffffffULL : capacity), bucketCount);
+}
+
+rt_status rt_build_photon_grid_async(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                                     uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes,
+                                     rt_photon* sorted, void* stream) {
+    return rt::buildGrid(photons, count, cellSize, bucketCount, counts, offsets, scan, scanBytes, sorted,
+                         static_cast<hipStream_t>(stream));
+}
+
+rt_status rt_build_photon_grid(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                               uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted) {
+    RT_TRY(rt::buildGrid(photons, count, cellSize, bucketCount, counts, offsets, scan, scanBytes, sorted, nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    return RT_SUCCESS;
+}
+
+rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uint32_t bucketCount, uint32_t* keys,
+                         void* stream) {
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return rt::failInvalid("bucketCount must be a power of two");
+    if (n == 0)
+        return RT_SUCCESS;
+    if (!positions || !keys)
+        return rt::failInvalid("positions / keys is null");
+    hipLaunchKernelGGL(rt::photonKeysKernel, dim3(rt::stridedGrid(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), positions, 3U, n, cellSize, bucketCount, keys);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+rt_status rt_photon_gather(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount, float radius,
+                           const float* qpos, const float* qnormal, uint32_t n, float* flux, void* stream) {
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return rt::failInvalid("bucketCount must be a power of two");
+    if (n == 0)
+        return RT_SUCCESS;
+    if (!cellStart || !qpos || !qnormal || !flux)
+        return rt::failInvalid("null pointer");
+    hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
+                       flux);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""GPU parity tests for the photon hash grid and the radius gather: the HIP
+path, called through the C ABI, against the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from raytracer_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def test_keys_bit_exact(engine, oracle):
+    cs, B = 0.0037, 1 << 22
+    pos = workloads.hash_edge_positions(cs)
+    keys = u32(engine.photon_keys(dev(pos), cs, B))
+    assert np.array_equal(keys, oracle.photon_keys(pos, cs, B))
+
+
+@pytest.mark.parametrize("n,B,cs", [(1, 1 << 4, 0.01), (63, 1 << 8, 0.01), (8192, 1 << 12, 0.004),
+                                     (8193, 1 << 12, 0.004), (100000, 1 << 16, 0.002), (300001, 1 << 22, 0.0015)])
+def test_grid_build_bit_exact(engine, oracle, n, B, cs):
+    import torch
+    ph = workloads.caustic_photons(n, seed=n)
+    grid = engine.PhotonGrid(n, B)
+    grid.build(dev(ph), cs, sync=True)
+    offsets, srt = oracle.build_photon_grid(ph, cs, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:n].cpu().numpy().view(np.uint32), srt.view(np.uint32))
+
+
+def test_grid_build_empty_and_library_workspace(engine, oracle):
+    import torch
+    B = 1 << 10
+    grid = engine.PhotonGrid(0, B, own_scratch=False)
+    grid.offsets.fill_(-1)
+    grid.build(torch.empty((0, 9), dtype=torch.float32, device="cuda"), 0.01, sync=True)
+    assert not u32(grid.offsets).any()
+    # scratch smaller than needed: the library falls back to its own workspace
+    ph = workloads.caustic_photons(5000, seed=4)
+    grid = engine.PhotonGrid(5000, B, own_scratch=False)
+    grid.build(dev(ph), 0.01, sync=True)
+    offsets, srt = oracle.build_photon_grid(ph, 0.01, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:5000].cpu().numpy(), srt)
+
+
+def test_grid_rejects_bad_bucket_count(engine):
+    import torch
+    with pytest.raises(engine.EngineError):
+        engine.PhotonGrid(16, 1000).build(torch.zeros((16, 9), device="cuda"), 0.01, sync=True)
+
+
+def test_gather_bit_exact(engine, oracle):
+    n, B, r = 400000, 1 << 18, 0.003
+    ph = workloads.caustic_photons(n, seed=21, extent=0.5)
+    grid = engine.PhotonGrid(n, B)
+    grid.build(dev(ph), r, sync=True)
+    qp, qn = workloads.gather_queries(50000, seed=22, extent=0.5)
+    # put some queries right on photons of the dense arcs
+    qp[:5000] = ph[-5000:, :3]
+    flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+    offsets, srt = oracle.build_photon_grid(ph, r, B)
+    ref = oracle.photon_gather(srt, offsets, B, r, qp, qn, threads=8)
+    assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
+    assert (flux != 0).any()
+
+
+def test_gather_collisions(engine, oracle):
+    # two buckets: nearly every neighbour cell repeats a bucket
+    ph = workloads.caustic_photons(3000, seed=2, extent=0.01)
+    r, B = 0.02, 2
+    grid = engine.PhotonGrid(3000, B)
+    grid.build(dev(ph), r, sync=True)
+    qp, qn = workloads.gather_queries(256, seed=3, extent=0.01)
+    flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+    offsets, srt = oracle.build_photon_grid(ph, r, B)
+    ref = oracle.photon_gather(srt, offsets, B, r, qp, qn)
+    assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
+
+
+def test_full_size_properties(engine, oracle):
+    """Reference-size map (2^23 photons, 2^22 buckets): properties that need no
+    full CPU pass, plus the oracle on a slice of the queries."""
+    import torch
+    n, B = workloads.PHOTON_CAPACITY, workloads.PHOTON_BUCKETS
+    r = 0.0015
+    ph = workloads.caustic_photons(n, seed=2)
+    dph = dev(ph)
+    grid = engine.PhotonGrid(n, B)
+    grid.build(dph, r, sync=True)
+    off = grid.offsets.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert off[0] == 0 and off[-1] == n and (np.diff(off) >= 0).all()
+    keys = u32(engine.photon_keys(dph[:, :3].contiguous(), r, B))
+    assert np.array_equal(np.diff(off), np.bincount(keys, minlength=B))
+    skeys = u32(engine.photon_keys(grid.sorted[:, :3].contiguous(), r, B))
+    assert (np.diff(skeys.astype(np.int64)) >= 0).all()
+    # a permutation: the multiset of rows is unchanged (checksum of row checksums)
+    rows_in = ph.view(np.uint32).astype(np.uint64)
+    rows_out = grid.sorted.cpu().numpy().view(np.uint32).astype(np.uint64)
+    w = np.arange(1, 10, dtype=np.uint64) * np.uint64(0x9e3779b1)
+    assert (rows_in * w).sum(1).sum() == (rows_out * w).sum(1).sum()
+    # stability: inside a bucket the input order is kept
+    order = np.argsort(keys, kind="stable")
+    sample = np.random.default_rng(0).integers(0, n, 20000)
+    assert np.array_equal(rows_out[sample], rows_in[order[sample]])
+    # gather on a slice against the oracle run over the GPU-built grid
+    qp, qn = workloads.gather_queries(20000, seed=8)
+    flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+    ref = oracle.photon_gather(grid.sorted.cpu().numpy(), off.astype(np.uint32), B, r, qp, qn, threads=8)
+    assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
