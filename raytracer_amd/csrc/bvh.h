@@ -7,6 +7,8 @@
 
 #include "common.h"
 
+#include <vector>
+
 namespace rt {
 
 constexpr int kWide = 8;          // children per node

@@ -207,13 +207,8 @@ __global__ __launch_bounds__(256) void refitKernel(const uint32_t* left, const u
         if (atomicAdd(&arrivals[node], 1U) == 0U)
             return;
         __threadfence();
-        const volatile Box4* vb = bounds;
-        Box4 a, b;
-        const uint32_t l = left[node], r = right[node];
-        a.lo = make_float4(vb[l].lo.x, vb[l].lo.y, vb[l].lo.z, 0.0f);
-        a.hi = make_float4(vb[l].hi.x, vb[l].hi.y, vb[l].hi.z, 0.0f);
-        b.lo = make_float4(vb[r].lo.x, vb[r].lo.y, vb[r].lo.z, 0.0f);
-        b.hi = make_float4(vb[r].hi.x, vb[r].hi.y, vb[r].hi.z, 0.0f);
+        const Box4 a = bounds[left[node]];
+        const Box4 b = bounds[right[node]];
         bounds[node] = merge(a, b);
         node = parent[node];
     }
@@ -347,8 +342,7 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
     if (rootBox && e == 0)
         *rootBox = all;
 
-    WideNode node;
-    std::memset(&node, 0, sizeof(node));
+    WideNode node = {};
     const float lo[3] = {all.lo.x, all.lo.y, all.lo.z};
     const float hi[3] = {all.hi.x, all.hi.y, all.hi.z};
 #pragma unroll
@@ -616,7 +610,8 @@ float scaleOfHost(uint8_t e) {
 // the largest box; a group of one instance is a leaf child.
 struct TopBuilder {
     const std::vector<Aabb>& boxes;
-    std::vector<uint32_t> order;      // instance permutation, leaf items refer to it
+    std::vector<uint32_t> order;      // instance permutation the splits work on
+    std::vector<uint32_t> items;      // instance index per leaf item slot, contiguous per node
     std::vector<WideNode> nodes;
     uint32_t depth = 0;
 
@@ -708,11 +703,9 @@ struct TopBuilder {
         const uint32_t childBase = static_cast<uint32_t>(nodes.size());
         nodes.resize(nodes.size() + internal);
         node.childBase = childBase;
-        // leaf items of one node must be contiguous in `order`: groups are in
-        // range order and cover [group.first, group.first + group.count), so
-        // items are addressed relative to the node's first instance
-        node.primBase = group.first;
-        uint32_t slot = 0;
+        // the leaf items of one node take consecutive slots of `items`
+        node.primBase = static_cast<uint32_t>(items.size());
+        uint32_t slot = 0, itemSlot = 0;
         std::vector<std::pair<uint32_t, Group>> pending;
         for (size_t k = 0; k < groups.size(); ++k) {
             const Group& g = groups[k];
@@ -735,8 +728,9 @@ struct TopBuilder {
                 pending.emplace_back(childBase + slot, g);
                 ++slot;
             } else {
-                node.meta[k] = static_cast<uint8_t>(1U << 5 | 0U);
-                // single instances are addressed through a per-child base: see below
+                node.meta[k] = static_cast<uint8_t>(1U << 5 | itemSlot);
+                items.push_back(order[g.first]);
+                ++itemSlot;
             }
         }
         nodes[self] = node;
@@ -744,6 +738,50 @@ struct TopBuilder {
             build(p.first, p.second, level + 1);
     }
 };
+
+rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStream_t stream, rt_scene* scene) {
+    std::vector<Aabb> boxes(count);
+    std::vector<InstanceRecord> records(count);
+    scene->inverses.resize(static_cast<size_t>(count) * 12);
+    for (uint32_t i = 0; i < count; ++i) {
+        const rt_instance_desc& d = instances[i];
+        if (!d.blas)
+            return failInvalid("instance without a bottom-level structure");
+        if (d.blas->device != scene->device)
+            return failInvalid("bottom-level structure lives on another device");
+        InstanceRecord& r = records[i];
+        std::memset(&r, 0, sizeof(r));
+        invertAffine(d.transform, r.toObject);
+        std::memcpy(&scene->inverses[static_cast<size_t>(i) * 12], r.toObject, sizeof(float) * 12);
+        r.nodes = d.blas->nodes;
+        r.triangles = d.blas->triangles;
+        r.instanceId = d.instanceId;
+        r.geometry = d.geometry;
+        boxes[i] = instanceBox(d.transform, d.blas->bounds);
+        scene->blasNodes += d.blas->nodeCount;
+        scene->triangles += d.blas->triangleCount;
+        scene->blasDepth = std::max(scene->blasDepth, d.blas->depth);
+    }
+    TopBuilder builder(boxes);
+    builder.nodes.resize(1);
+    builder.build(0, {0, count, builder.boxOf(0, count)}, 0);
+    std::vector<InstanceRecord> ordered(count);
+    if (builder.items.size() != count)
+        return failInvalid("top-level build lost instances");
+    for (uint32_t k = 0; k < count; ++k)
+        ordered[k] = records[builder.items[k]];
+    scene->nodeCount = builder.nodes.size();
+    scene->instanceCount = count;
+    scene->depth = builder.depth;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->nodes), sizeof(WideNode) * builder.nodes.size()));
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * count));
+    RT_HIP(hipMemcpyAsync(scene->nodes, builder.nodes.data(), sizeof(WideNode) * builder.nodes.size(),
+                          hipMemcpyHostToDevice, stream));
+    RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice,
+                          stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    return RT_SUCCESS;
+}
 
 }  // namespace
 }  // namespace rt
@@ -783,6 +821,57 @@ void rt_blas_destroy(rt_blas* blas) {
     if (blas->triangles)
         (void)hipFree(blas->triangles);
     delete blas;
+}
+
+rt_status rt_scene_build(const rt_instance_desc* instances, uint32_t instanceCount, void* stream, rt_scene** out) {
+    if (!out)
+        return failInvalid("out is null");
+    *out = nullptr;
+    if (!instances || instanceCount == 0)
+        return failInvalid("the scene has no geometry");  // renderer.cpp:217-218
+    auto* scene = new rt_scene();
+    RT_HIP(hipGetDevice(&scene->device));
+    const rt_status status = buildScene(instances, instanceCount, static_cast<hipStream_t>(stream), scene);
+    if (status != RT_SUCCESS) {
+        rt_scene_destroy(scene);
+        return status;
+    }
+    *out = scene;
+    return RT_SUCCESS;
+}
+
+void rt_scene_destroy(rt_scene* scene) {
+    if (!scene)
+        return;
+    if (scene->nodes)
+        (void)hipFree(scene->nodes);
+    if (scene->instances)
+        (void)hipFree(scene->instances);
+    delete scene;
+}
+
+uint64_t rt_scene_handle(const rt_scene* scene) {
+    return reinterpret_cast<uint64_t>(scene);
+}
+
+rt_status rt_scene_instance_inverse(const rt_scene* scene, uint32_t index, float* out12) {
+    if (!scene || !out12 || index >= scene->instanceCount)
+        return failInvalid("instance index");
+    std::memcpy(out12, &scene->inverses[static_cast<size_t>(index) * 12], sizeof(float) * 12);
+    return RT_SUCCESS;
+}
+
+rt_status rt_scene_stats(const rt_scene* scene, rt_bvh_stats* out) {
+    if (!scene || !out)
+        return failInvalid("null pointer");
+    out->nodeCount = scene->nodeCount + scene->blasNodes;
+    out->nodeBytes = out->nodeCount * sizeof(WideNode);
+    out->triangleCount = scene->triangles;
+    out->triangleBytes = scene->triangles * sizeof(PackedTriangle);
+    out->instanceCount = scene->instanceCount;
+    out->maxDepth = scene->depth + scene->blasDepth;
+    out->buildMilliseconds = scene->buildMilliseconds;
+    return RT_SUCCESS;
 }
 
 rt_status rt_blas_stats(const rt_blas* blas, rt_bvh_stats* out) {

@@ -56,7 +56,7 @@ __device__ inline uint32_t blockExclusiveScan(uint32_t value, uint32_t* waveSums
 
 // ---- exclusive prefix sum over uint32 -------------------------------------
 
-__global__ __launch_bounds__(kScanBlock) void scanReduceKernel(const uint32_t* in, size_t n, uint32_t* partials) {
+static __global__ __launch_bounds__(kScanBlock) void scanReduceKernel(const uint32_t* in, size_t n, uint32_t* partials) {
     __shared__ uint32_t waveSums[kScanBlock / 64];
     const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile;
     uint32_t sum = 0;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kScanBlock) void scanReduceKernel(const uint32_t* i
 }
 
 // One workgroup turns the per-tile sums into exclusive prefixes in place.
-__global__ __launch_bounds__(1024) void scanPartialsKernel(uint32_t* partials, uint32_t count) {
+static __global__ __launch_bounds__(1024) void scanPartialsKernel(uint32_t* partials, uint32_t count) {
     __shared__ uint32_t waveSums[1024 / 64];
     const uint32_t perThread = (count + 1023U) / 1024U;
     const uint32_t begin = min(count, threadIdx.x * perThread);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void scanPartialsKernel(uint32_t* partials, u
     }
 }
 
-__global__ __launch_bounds__(kScanBlock) void scanApplyKernel(const uint32_t* in, uint32_t* out, size_t n,
+static __global__ __launch_bounds__(kScanBlock) void scanApplyKernel(const uint32_t* in, uint32_t* out, size_t n,
                                                               const uint32_t* partials) {
     __shared__ uint32_t waveSums[kScanBlock / 64];
     // each thread owns kScanItems consecutive values
