@@ -77,6 +77,12 @@ rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uin
 rt_status rt_photon_gather(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount, float radius,
                            const float* qpos, const float* qnormal, uint32_t n, float* flux, void* stream);
 
+/* Same, and adds the number of photons read (the sum over queries of the sizes
+ * of the distinct buckets visited) to *visitedPhotons (device). */
+rt_status rt_photon_gather_counted(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+                                   float radius, const float* qpos, const float* qnormal, uint32_t n, float* flux,
+                                   uint64_t* visitedPhotons, void* stream);
+
 /* ------------------------------------------------------------------------
  * Acceleration structures — replace the OptiX GAS / IAS builds of
  * src/renderer.cpp:343-396 and :398-434
@@ -105,6 +111,11 @@ typedef struct rt_instance_desc {
  * host memory.  The BLASes must outlive the scene. */
 rt_status rt_scene_build(const rt_instance_desc* instances, uint32_t instanceCount, void* stream, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+/* The hit-group records of the shader binding table (src/renderer.cpp:649-660):
+ * one rt_hit_group_data per geometry, indexed by rt_instance_desc.geometry.
+ * `records` is host memory holding device pointers; the shading kernels read
+ * vertices, indices and the material index through it. */
+rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* records, uint32_t count);
 /* The 8-byte value stored in rt_launch_params.scene (src/gpu_shared.hpp:117). */
 uint64_t rt_scene_handle(const rt_scene* scene);
 /* world->object 3x4 (row-major) the engine uses for instance `index`. */
@@ -151,6 +162,44 @@ rt_status rt_trace_any(const rt_scene* scene, const rt_float4* originTmin, const
 rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* originTmin,
                                    const rt_float4* directionTmax, uint32_t n, rt_ray_hit* hits, uint32_t* instance,
                                    uint64_t* counters4, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Wavefront pipeline — replaces the two optixLaunch calls of
+ * src/renderer.cpp:748-750 (photon pass) and :790-791 (camera sample), i.e. the
+ * ray-generation programs __raygen__photons and __raygen__render of
+ * src/device.cu:768-861 and :863-1075
+ * ------------------------------------------------------------------------ */
+
+typedef struct rt_wavefront rt_wavefront; /* ray queues and per-path state for up to maxPaths paths */
+rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out);
+void rt_wavefront_destroy(rt_wavefront* wavefront);
+
+/* One camera sample (params->sample) for the pixels [pixelBegin, pixelEnd) in
+ * row-major order, row 0 at the bottom: generate, then maxDepth rounds of extend
+ * (closest hit) / shade / shadow, then the running-mean accumulation into the
+ * seven float4 buffers and the tone-mapped byte image of `params`
+ * (src/device.cu:1043-1074).  `params` is host memory; every pointer in it is a
+ * device pointer and params->scene is rt_scene_handle() of a scene that has its
+ * geometry records set.  pixelEnd - pixelBegin must not exceed maxPaths.
+ * Enqueued on `stream`; returns without waiting (src/renderer.cpp:790-793). */
+rt_status rt_render_sample(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t pixelBegin,
+                           uint32_t pixelEnd, void* stream);
+
+/* The photon pass for emission indices [firstEmission, firstEmission +
+ * emissionCount) of pass params->photonPass: photons are appended to
+ * params->photons behind *params->photonCount in emission order (the reference
+ * appends in atomic order, src/device.cu:716), and *params->photonCount grows by
+ * the number of photons the tracer wanted to store, which can exceed
+ * params->photonCapacity as upstream (src/renderer.cpp:755-769).  The caller
+ * zeroes *params->photonCount before the first range of a pass
+ * (src/renderer.cpp:743).  Enqueued on `stream`. */
+rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
+                           uint32_t emissionCount, void* stream);
+
+/* Copies the running counters to out4 (host): [0] rays through the extend
+ * stage, [1] shadow rays, [2] caustic gather queries, [3] photons read by them.
+ * Synchronises `stream`; reset != 0 zeroes the counters afterwards. */
+rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out4, int reset, void* stream);
 
 #ifdef __cplusplus
 }

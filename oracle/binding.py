@@ -39,6 +39,8 @@ def load():
         "orc_trace_closest": (None, [_vp, _vp, _vp, _u32, C.c_int, C.c_int, _vp, _vp, _vp]),
         "orc_trace_any": (None, [_vp, _vp, _vp, _u32, C.c_int, C.c_int, _vp]),
         "orc_shade_hits": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+        "orc_render_sample": (None, [_vp, _vp, _u32, _u32, C.c_int]),
+        "orc_trace_photons": (_u32, [_vp, _vp, _u32, _u32, _vp, _u32, C.c_int]),
     }
     for name, (restype, argtypes) in sig.items():
         fn = getattr(lib, name)
@@ -164,6 +166,16 @@ class Scene:
         hits = np.zeros((o.shape[0], 96), dtype=np.uint8)
         self.lib.orc_shade_hits(self.handle, _p(o), _p(d), _p(t), _p(p), _p(i), o.shape[0], _p(hits))
         return hits
+
+    def render_sample(self, params, pixel_begin, pixel_end, threads=1):
+        """params: a ctypes rt_launch_params whose pointers are HOST addresses."""
+        self.lib.orc_render_sample(self.handle, C.byref(params), pixel_begin, pixel_end, threads)
+
+    def trace_photons(self, params, first, count, capacity, threads=1):
+        """Returns (photons (n, 9) float32 in emission order, wanted count)."""
+        out = np.zeros((capacity, 9), dtype=np.float32)
+        wanted = self.lib.orc_trace_photons(self.handle, C.byref(params), first, count, _p(out), capacity, threads)
+        return out[:min(wanted, capacity)], int(wanted)
 
     def close(self):
         if self.handle:

@@ -85,6 +85,19 @@ void orc_trace_any(const orc_scene*, const float* org_tmin, const float* dir_tma
 void orc_shade_hits(const orc_scene*, const float* org_tmin, const float* dir_tmax, const float* tuv,
                     const uint32_t* prim, const uint32_t* inst, uint32_t n, rt_hit* hits);
 
+/* ---- integrator (device.cu:863-1075) and photon tracer (device.cu:768-861) --
+ * Every pointer inside `params` is a HOST pointer here; params->scene is
+ * ignored.  orc_render_sample runs sample params->sample for the pixels
+ * [pixelBegin, pixelEnd) and updates the seven accumulation buffers and the
+ * byte image exactly as device.cu:1043-1074 does. */
+void orc_render_sample(const orc_scene* scene, const rt_launch_params* params, uint32_t pixelBegin, uint32_t pixelEnd,
+                       int threads);
+/* Emission indices [first, first + count) of pass params->photonPass; stored
+ * photons go to `out` in emission order (at most `capacity`); returns how many
+ * the tracer wanted to store. */
+uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* params, uint32_t first, uint32_t count,
+                           rt_photon* out, uint32_t capacity, int threads);
+
 #ifdef __cplusplus
 }
 #endif

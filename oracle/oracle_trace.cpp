@@ -32,6 +32,7 @@
 //     u = V*rcp (weight of v1), v = W*rcp (weight of v2).
 //   closest hit: smallest t; exact ties go to the lowest (instance, primitive).
 #include "oracle.h"
+#include "oracle_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -445,9 +446,93 @@ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x
 V3 normalize(V3 a) { return scale(a, 1.0f / std::sqrt(dot(a, a))); }
 V3 f3(const rt_float3& a) { return {a.x, a.y, a.z}; }
 
+// device.cu:1081-1145.  optixTransformNormalFromObjectToWorldSpace multiplies
+// by the transpose of the world->object 3x3; optixTransformVectorFrom... by the
+// object->world 3x3.  Their internal association order is not published; the
+// row-by-row (a*x + b*y) + c*z order is used here.
+void shadeOne(const Scene& scene, V3 origin, V3 ray, float t, float bx, float by, uint32_t prim, uint32_t inst,
+              rt_hit& hit) {
+    std::memset(&hit, 0, sizeof(hit));  // device.cu:390
+    if (prim == 0xffffffffU) return;    // device.cu:1077-1079
+    const Instance& instance = scene.instances[inst];
+    const Geometry& g = scene.geometries[instance.geometry];
+    const size_t base = 3 * static_cast<size_t>(prim);
+    const rt_gpu_vertex& v0 = g.vertices[g.indices[base]];
+    const rt_gpu_vertex& v1 = g.vertices[g.indices[base + 1]];
+    const rt_gpu_vertex& v2 = g.vertices[g.indices[base + 2]];
+    const float b0 = 1.0f - bx - by;  // device.cu:1086
+    V3 normal = add(add(scale(f3(v0.normal), b0), scale(f3(v1.normal), bx)), scale(f3(v2.normal), by));
+    if (dot(normal, normal) < 1e-12f)
+        normal = cross(sub(f3(v1.position), f3(v0.position)), sub(f3(v2.position), f3(v0.position)));
+    const V3 objectNormal = normalize(normal);
+    const float* w2o = instance.toObject;
+    // transpose of the world->object 3x3
+    normal = normalize(V3{(w2o[0] * normal.x + w2o[4] * normal.y) + w2o[8] * normal.z,
+                          (w2o[1] * normal.x + w2o[5] * normal.y) + w2o[9] * normal.z,
+                          (w2o[2] * normal.x + w2o[6] * normal.y) + w2o[10] * normal.z});
+    hit.frontFace = dot(normal, ray) < 0.0f;  // device.cu:1099
+    const V3 facing = hit.frontFace ? normal : scale(normal, -1.0f);
+    hit.normal = {facing.x, facing.y, facing.z};
+    float tw = v0.tangent.w * b0 + v1.tangent.w * bx + v2.tangent.w * by;
+    V3 tangent{v0.tangent.x * b0 + v1.tangent.x * bx + v2.tangent.x * by,
+               v0.tangent.y * b0 + v1.tangent.y * bx + v2.tangent.y * by,
+               v0.tangent.z * b0 + v1.tangent.z * bx + v2.tangent.z * by};
+    if (dot(tangent, tangent) < 1e-12f) {  // device.cu:1111-1123
+        const float d1x = v1.uv.x - v0.uv.x, d1y = v1.uv.y - v0.uv.y;
+        const float d2x = v2.uv.x - v0.uv.x, d2y = v2.uv.y - v0.uv.y;
+        const float determinant = d1x * d2y - d1y * d2x;
+        if (std::fabs(determinant) > 1e-8f) {
+            const V3 e1 = sub(f3(v1.position), f3(v0.position));
+            const V3 e2 = sub(f3(v2.position), f3(v0.position));
+            tangent = scale(sub(scale(e1, d2y), scale(e2, d1y)), 1.0f / determinant);
+        } else {
+            tangent = cross(std::fabs(objectNormal.x) > 0.5f ? V3{0.0f, 1.0f, 0.0f} : V3{1.0f, 0.0f, 0.0f},
+                            objectNormal);
+        }
+        tw = 1.0f;
+    }
+    tangent = xformVector(instance.toWorld, tangent);  // device.cu:1124-1125
+    tangent = normalize(sub(tangent, scale(facing, dot(tangent, facing))));
+    hit.tangent.x = tangent.x;
+    hit.tangent.y = tangent.y;
+    hit.tangent.z = tangent.z;
+    hit.tangent.w = tw < 0.0f ? -1.0f : 1.0f;
+    hit.uv.x = v0.uv.x * b0 + v1.uv.x * bx + v2.uv.x * by;
+    hit.uv.y = v0.uv.y * b0 + v1.uv.y * bx + v2.uv.y * by;
+    hit.uv1.x = v0.uv1.x * b0 + v1.uv1.x * bx + v2.uv1.x * by;
+    hit.uv1.y = v0.uv1.y * b0 + v1.uv1.y * bx + v2.uv1.y * by;
+    const V3 p = add(origin, scale(ray, t));  // device.cu:1139
+    hit.position = {p.x, p.y, p.z};
+    hit.distance = t;
+    hit.material = g.material;
+    hit.instance = inst;
+    hit.primitive = prim;
+    hit.found = 1;
+}
+
 }  // namespace
 
 struct orc_scene : Scene {};
+
+namespace orc {
+
+// trace() of device.cu:388-397 followed by the closest-hit / miss programs.
+rt_hit traceHit(const orc_scene* scene, const float origin[3], const float direction[3], float tmax) {
+    const float o4[4] = {origin[0], origin[1], origin[2], 0.001f};
+    const float d4[4] = {direction[0], direction[1], direction[2], tmax};
+    const Best best = traceScene(*scene, o4, d4, true, false);
+    rt_hit hit;
+    shadeOne(*scene, V3{origin[0], origin[1], origin[2]}, V3{direction[0], direction[1], direction[2]}, best.t, best.u,
+             best.v, best.prim, best.inst, hit);
+    return hit;
+}
+
+const rt_gpu_vertex* geometryVertices(const orc_scene* scene, uint32_t geometry, uint32_t* count) {
+    *count = static_cast<uint32_t>(scene->geometries[geometry].vertices.size());
+    return scene->geometries[geometry].vertices.data();
+}
+
+}  // namespace orc
 
 extern "C" {
 
@@ -536,77 +621,13 @@ void orc_trace_any(const orc_scene* s, const float* org_tmin, const float* dir_t
     });
 }
 
-// device.cu:1081-1145.  optixTransformNormalFromObjectToWorldSpace multiplies
-// by the transpose of the world->object 3x3; optixTransformVectorFrom... by the
-// object->world 3x3.  Their internal association order is not published; the
-// row-by-row (a*x + b*y) + c*z order is used here.
 void orc_shade_hits(const orc_scene* s, const float* org_tmin, const float* dir_tmax, const float* tuv,
                     const uint32_t* prim, const uint32_t* inst, uint32_t n, rt_hit* hits) {
     for (uint32_t i = 0; i < n; ++i) {
-        rt_hit& hit = hits[i];
-        std::memset(&hit, 0, sizeof(hit));  // device.cu:390
-        if (prim[i] == 0xffffffffU) continue;  // device.cu:1077-1079
-        const Instance& instance = s->instances[inst[i]];
-        const Geometry& g = s->geometries[instance.geometry];
-        const size_t base = 3 * static_cast<size_t>(prim[i]);
-        const rt_gpu_vertex& v0 = g.vertices[g.indices[base]];
-        const rt_gpu_vertex& v1 = g.vertices[g.indices[base + 1]];
-        const rt_gpu_vertex& v2 = g.vertices[g.indices[base + 2]];
-        const float t = tuv[3 * static_cast<size_t>(i)];
-        const float bx = tuv[3 * static_cast<size_t>(i) + 1];
-        const float by = tuv[3 * static_cast<size_t>(i) + 2];
-        const float b0 = 1.0f - bx - by;  // device.cu:1086
-        V3 normal = add(add(scale(f3(v0.normal), b0), scale(f3(v1.normal), bx)), scale(f3(v2.normal), by));
-        if (dot(normal, normal) < 1e-12f)
-            normal = cross(sub(f3(v1.position), f3(v0.position)), sub(f3(v2.position), f3(v0.position)));
-        const V3 objectNormal = normalize(normal);
-        const float* w2o = instance.toObject;
-        // transpose of the world->object 3x3
-        normal = normalize(V3{(w2o[0] * normal.x + w2o[4] * normal.y) + w2o[8] * normal.z,
-                              (w2o[1] * normal.x + w2o[5] * normal.y) + w2o[9] * normal.z,
-                              (w2o[2] * normal.x + w2o[6] * normal.y) + w2o[10] * normal.z});
-        const V3 ray{dir_tmax[4 * static_cast<size_t>(i)], dir_tmax[4 * static_cast<size_t>(i) + 1],
-                     dir_tmax[4 * static_cast<size_t>(i) + 2]};
-        const V3 origin{org_tmin[4 * static_cast<size_t>(i)], org_tmin[4 * static_cast<size_t>(i) + 1],
-                        org_tmin[4 * static_cast<size_t>(i) + 2]};
-        hit.frontFace = dot(normal, ray) < 0.0f;  // device.cu:1099
-        const V3 facing = hit.frontFace ? normal : scale(normal, -1.0f);
-        hit.normal = {facing.x, facing.y, facing.z};
-        float tw = v0.tangent.w * b0 + v1.tangent.w * bx + v2.tangent.w * by;
-        V3 tangent{v0.tangent.x * b0 + v1.tangent.x * bx + v2.tangent.x * by,
-                   v0.tangent.y * b0 + v1.tangent.y * bx + v2.tangent.y * by,
-                   v0.tangent.z * b0 + v1.tangent.z * bx + v2.tangent.z * by};
-        if (dot(tangent, tangent) < 1e-12f) {  // device.cu:1111-1123
-            const float d1x = v1.uv.x - v0.uv.x, d1y = v1.uv.y - v0.uv.y;
-            const float d2x = v2.uv.x - v0.uv.x, d2y = v2.uv.y - v0.uv.y;
-            const float determinant = d1x * d2y - d1y * d2x;
-            if (std::fabs(determinant) > 1e-8f) {
-                const V3 e1 = sub(f3(v1.position), f3(v0.position));
-                const V3 e2 = sub(f3(v2.position), f3(v0.position));
-                tangent = scale(sub(scale(e1, d2y), scale(e2, d1y)), 1.0f / determinant);
-            } else {
-                tangent = cross(std::fabs(objectNormal.x) > 0.5f ? V3{0.0f, 1.0f, 0.0f} : V3{1.0f, 0.0f, 0.0f},
-                                objectNormal);
-            }
-            tw = 1.0f;
-        }
-        tangent = xformVector(instance.toWorld, tangent);  // device.cu:1124-1125
-        tangent = normalize(sub(tangent, scale(facing, dot(tangent, facing))));
-        hit.tangent.x = tangent.x;
-        hit.tangent.y = tangent.y;
-        hit.tangent.z = tangent.z;
-        hit.tangent.w = tw < 0.0f ? -1.0f : 1.0f;
-        hit.uv.x = v0.uv.x * b0 + v1.uv.x * bx + v2.uv.x * by;
-        hit.uv.y = v0.uv.y * b0 + v1.uv.y * bx + v2.uv.y * by;
-        hit.uv1.x = v0.uv1.x * b0 + v1.uv1.x * bx + v2.uv1.x * by;
-        hit.uv1.y = v0.uv1.y * b0 + v1.uv1.y * bx + v2.uv1.y * by;
-        const V3 p = add(origin, scale(ray, t));  // device.cu:1139
-        hit.position = {p.x, p.y, p.z};
-        hit.distance = t;
-        hit.material = g.material;
-        hit.instance = inst[i];
-        hit.primitive = prim[i];
-        hit.found = 1;
+        const size_t k = static_cast<size_t>(i);
+        const V3 origin{org_tmin[4 * k], org_tmin[4 * k + 1], org_tmin[4 * k + 2]};
+        const V3 ray{dir_tmax[4 * k], dir_tmax[4 * k + 1], dir_tmax[4 * k + 2]};
+        shadeOne(*s, origin, ray, tuv[3 * k], tuv[3 * k + 1], tuv[3 * k + 2], prim[i], inst[i], hits[i]);
     }
 }
 

@@ -55,6 +55,14 @@ struct alignas(16) InstanceRecord {
 };
 static_assert(sizeof(InstanceRecord) == 80, "instance record is 80 bytes");
 
+// Shading-side record of an instance, indexed by instance id.
+struct ShadeInstance {
+    float toObject[12];
+    float toWorld[12];
+    uint32_t geometry;
+    uint32_t pad[3];
+};
+
 struct Aabb {
     float lo[3];
     float hi[3];
@@ -82,6 +90,10 @@ struct rt_scene {
     uint32_t depth = 0;
     uint64_t blasNodes = 0, blasNodeBytes = 0, triangles = 0, triangleBytes = 0;
     uint32_t blasDepth = 0;
+    rt::ShadeInstance* shadeInstances = nullptr;  // indexed by instance id
+    uint32_t shadeInstanceCount = 0;
+    rt_hit_group_data* hitGroups = nullptr;       // one record per geometry (rt_scene_set_geometry)
+    uint32_t hitGroupCount = 0;
     std::vector<float> inverses;            // 12 floats per instance (host copy)
     float buildMilliseconds = 0.0f;
 };

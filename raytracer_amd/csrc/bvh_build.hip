@@ -779,6 +779,24 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
                           hipMemcpyHostToDevice, stream));
     RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice,
                           stream));
+    // shading-side table indexed by instance id
+    uint32_t maxId = 0;
+    for (uint32_t i = 0; i < count; ++i)
+        maxId = std::max(maxId, instances[i].instanceId);
+    if (maxId > (1U << 26))
+        return failInvalid("instance ids must be small enough to index a table");
+    std::vector<ShadeInstance> shade(static_cast<size_t>(maxId) + 1);
+    std::memset(shade.data(), 0, shade.size() * sizeof(ShadeInstance));
+    for (uint32_t i = 0; i < count; ++i) {
+        ShadeInstance& si = shade[instances[i].instanceId];
+        std::memcpy(si.toObject, records[i].toObject, sizeof(si.toObject));
+        std::memcpy(si.toWorld, instances[i].transform, sizeof(si.toWorld));
+        si.geometry = instances[i].geometry;
+    }
+    scene->shadeInstanceCount = maxId + 1;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->shadeInstances), sizeof(ShadeInstance) * shade.size()));
+    RT_HIP(hipMemcpyAsync(scene->shadeInstances, shade.data(), sizeof(ShadeInstance) * shade.size(),
+                          hipMemcpyHostToDevice, stream));
     RT_HIP(hipStreamSynchronize(stream));
     return RT_SUCCESS;
 }
@@ -847,7 +865,24 @@ void rt_scene_destroy(rt_scene* scene) {
         (void)hipFree(scene->nodes);
     if (scene->instances)
         (void)hipFree(scene->instances);
+    if (scene->shadeInstances)
+        (void)hipFree(scene->shadeInstances);
+    if (scene->hitGroups)
+        (void)hipFree(scene->hitGroups);
     delete scene;
+}
+
+rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* records, uint32_t count) {
+    if (!scene || !records || count == 0)
+        return failInvalid("null pointer");
+    if (scene->hitGroups) {
+        RT_HIP(hipFree(scene->hitGroups));
+        scene->hitGroups = nullptr;
+    }
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->hitGroups), sizeof(rt_hit_group_data) * count));
+    RT_HIP(hipMemcpy(scene->hitGroups, records, sizeof(rt_hit_group_data) * count, hipMemcpyHostToDevice));
+    scene->hitGroupCount = count;
+    return RT_SUCCESS;
 }
 
 uint64_t rt_scene_handle(const rt_scene* scene) {

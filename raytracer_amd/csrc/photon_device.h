@@ -1,0 +1,86 @@
+// Device-side photon hash and radius gather, shared by the grid kernels and the
+// shading kernels.  Restates src/photon_hash.cuh:10-24 and the gather loop of
+// src/device.cu:729-762 of the reference.
+#pragma once
+
+#include "common.h"
+
+namespace rt {
+
+// float -> int32, saturating, NaN -> 0 (the conversion the reference's
+// static_cast<int>(floorf(..)) performs on the GPU; spelled out because an
+// out-of-range cast is undefined for the compiler).
+__device__ inline int toInt(float v) {
+    if (v != v)
+        return 0;
+    if (v >= 2147483648.0f)
+        return 2147483647;
+    if (v <= -2147483648.0f)
+        return -2147483647 - 1;
+    return static_cast<int>(v);
+}
+
+// src/photon_hash.cuh:10-24.  The division is the correctly rounded IEEE one.
+__device__ inline uint32_t bucketOfCell(int x, int y, int z, uint32_t bucketCount) {
+    const uint32_t hash = static_cast<uint32_t>(x) * 73856093U ^ static_cast<uint32_t>(y) * 19349663U ^
+                          static_cast<uint32_t>(z) * 83492791U;
+    return hash & (bucketCount - 1U);
+}
+
+__device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float cellSize, uint32_t bucketCount) {
+    return bucketOfCell(toInt(floorf(px / cellSize)), toInt(floorf(py / cellSize)), toInt(floorf(pz / cellSize)),
+                        bucketCount);
+}
+
+// Flux sum of one query in the reference's own order (cells z, y, x from -1 to
+// 1, a bucket reached twice counted once, photons in stored order), so the
+// float sums match a scalar evaluation bit for bit.  `visitedPhotons`, when not
+// null, receives the number of photons read.
+__device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+                                  float radius, float hx, float hy, float hz, float nx, float ny, float nz, float& fx,
+                                  float& fy, float& fz, uint32_t* visitedPhotons) {
+    const int cx = toInt(floorf(hx / radius));
+    const int cy = toInt(floorf(hy / radius));
+    const int cz = toInt(floorf(hz / radius));
+    const float radiusSquared = radius * radius;
+    fx = 0.0f;
+    fy = 0.0f;
+    fz = 0.0f;
+    uint32_t read = 0;
+    uint32_t visited[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        visited[c] = bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
+                                  static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
+                                  static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+    }
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        bool seen = false;
+#pragma unroll
+        for (int p = 0; p < c; ++p)
+            seen |= visited[p] == visited[c];
+        if (seen)
+            continue;
+        const uint32_t begin = cellStart[visited[c]];
+        const uint32_t end = cellStart[visited[c] + 1U];
+        read += end - begin;
+        for (uint32_t index = begin; index < end; ++index) {
+            const float* p = reinterpret_cast<const float*>(sorted + index);
+            const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
+            const float distanceSquared = ox * ox + oy * oy + oz * oz;
+            const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
+            if (distanceSquared >= radiusSquared || cosine < 0.7f)
+                continue;
+            const float weight = 1.0f - distanceSquared / radiusSquared;
+            fx = fx + p[3] * weight;
+            fy = fy + p[4] * weight;
+            fz = fz + p[5] * weight;
+        }
+    }
+    if (visitedPhotons)
+        *visitedPhotons = read;
+}
+
+}  // namespace rt

@@ -7,37 +7,13 @@
 // sort keeps photons of one bucket in input order, so the grid and every gather
 // sum are reproducible.
 #include "common.h"
+#include "photon_device.h"
 #include "radix_sort.h"
 
 #include <mutex>
 
 namespace rt {
 namespace {
-
-// float -> int32, saturating, NaN -> 0 (the conversion the reference's
-// static_cast<int>(floorf(..)) performs on the GPU; spelled out because an
-// out-of-range cast is undefined for the compiler).
-__device__ inline int toInt(float v) {
-    if (v != v)
-        return 0;
-    if (v >= 2147483648.0f)
-        return 2147483647;
-    if (v <= -2147483648.0f)
-        return -2147483647 - 1;
-    return static_cast<int>(v);
-}
-
-// src/photon_hash.cuh:10-24.  The division is the correctly rounded IEEE one.
-__device__ inline uint32_t bucketOfCell(int x, int y, int z, uint32_t bucketCount) {
-    const uint32_t hash = static_cast<uint32_t>(x) * 73856093U ^ static_cast<uint32_t>(y) * 19349663U ^
-                          static_cast<uint32_t>(z) * 83492791U;
-    return hash & (bucketCount - 1U);
-}
-
-__device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float cellSize, uint32_t bucketCount) {
-    return bucketOfCell(toInt(floorf(px / cellSize)), toInt(floorf(py / cellSize)), toInt(floorf(pz / cellSize)),
-                        bucketCount);
-}
 
 // positions: float3 at `stride` floats.
 __global__ __launch_bounds__(256) void photonKeysKernel(const float* positions, uint32_t stride, uint32_t n,
@@ -98,57 +74,29 @@ __global__ __launch_bounds__(256) void photonReorderKernel(const rt_photon* phot
     }
 }
 
-// One query per lane, the loop of src/device.cu:729-762 in its own order, so
-// the float sums match a scalar evaluation bit for bit.
+// One query per lane.
 __global__ __launch_bounds__(256) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
                                                           uint32_t bucketCount, float radius, const float* qpos,
-                                                          const float* qnormal, uint32_t n, float* flux) {
+                                                          const float* qnormal, uint32_t n, float* flux,
+                                                          unsigned long long* visitedTotal) {
     const size_t q = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (q >= n)
-        return;
-    const float hx = qpos[3 * q], hy = qpos[3 * q + 1], hz = qpos[3 * q + 2];
-    const float nx = qnormal[3 * q], ny = qnormal[3 * q + 1], nz = qnormal[3 * q + 2];
-    const int cx = toInt(floorf(hx / radius));
-    const int cy = toInt(floorf(hy / radius));
-    const int cz = toInt(floorf(hz / radius));
-    const float radiusSquared = radius * radius;
-    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-    // The 27 buckets first (two cells can share a bucket: keep the first), then
-    // their ranges, so the range loads are independent of the photon loop.
-    uint32_t visited[27];
-#pragma unroll
-    for (int c = 0; c < 27; ++c) {
-        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-        visited[c] = bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
-                                  static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
-                                  static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+    uint32_t read = 0;
+    if (q < n) {
+        float fx, fy, fz;
+        gatherFlux(sorted, cellStart, bucketCount, radius, qpos[3 * q], qpos[3 * q + 1], qpos[3 * q + 2], qnormal[3 * q],
+                   qnormal[3 * q + 1], qnormal[3 * q + 2], fx, fy, fz, visitedTotal ? &read : nullptr);
+        flux[3 * q] = fx;
+        flux[3 * q + 1] = fy;
+        flux[3 * q + 2] = fz;
     }
+    if (visitedTotal) {
+        unsigned long long sum = read;
 #pragma unroll
-    for (int c = 0; c < 27; ++c) {
-        bool seen = false;
-#pragma unroll
-        for (int p = 0; p < c; ++p)
-            seen |= visited[p] == visited[c];
-        if (seen)
-            continue;
-        const uint32_t begin = cellStart[visited[c]];
-        const uint32_t end = cellStart[visited[c] + 1U];
-        for (uint32_t index = begin; index < end; ++index) {
-            const float* p = reinterpret_cast<const float*>(sorted + index);
-            const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
-            const float distanceSquared = ox * ox + oy * oy + oz * oz;
-            const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
-            if (distanceSquared >= radiusSquared || cosine < 0.7f)
-                continue;
-            const float weight = 1.0f - distanceSquared / radiusSquared;
-            fx = fx + p[3] * weight;
-            fy = fy + p[4] * weight;
-            fz = fz + p[5] * weight;
-        }
+        for (int delta = 32; delta >= 1; delta >>= 1)
+            sum += __shfl_down(sum, delta, 64);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(visitedTotal, sum);
     }
-    flux[3 * q] = fx;
-    flux[3 * q + 1] = fy;
-    flux[3 * q + 2] = fz;
 }
 
 struct GridScratch {
@@ -303,7 +251,23 @@ rt_status rt_photon_gather(const rt_photon* sorted, const uint32_t* cellStart, u
         return rt::failInvalid("null pointer");
     hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
-                       flux);
+                       flux, static_cast<unsigned long long*>(nullptr));
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+rt_status rt_photon_gather_counted(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+                                   float radius, const float* qpos, const float* qnormal, uint32_t n, float* flux,
+                                   uint64_t* visitedPhotons, void* stream) {
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return rt::failInvalid("bucketCount must be a power of two");
+    if (n == 0)
+        return RT_SUCCESS;
+    if (!cellStart || !qpos || !qnormal || !flux || !visitedPhotons)
+        return rt::failInvalid("null pointer");
+    hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
+                       flux, reinterpret_cast<unsigned long long*>(visitedPhotons));
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }

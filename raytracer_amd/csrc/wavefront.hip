@@ -1,0 +1,775 @@
+// Wavefront path tracing and photon tracing for gfx950.
+//
+// Replaces the two OptiX ray-generation programs of the reference - the camera
+// path integrator __raygen__render (src/device.cu:863-1075) and the photon
+// tracer __raygen__photons (src/device.cu:768-861) - by queues of rays that
+// move through separate kernels:
+//
+//   generate -> [ extend (closest hit) -> shade -> shadow ] x maxDepth -> accumulate
+//
+// A path keeps its state in arrays indexed by its pixel, so only the ray itself
+// is moved when the queue is compacted.  Survivors get their slot in the next
+// queue from a wave ballot, a workgroup prefix and one atomic per workgroup.
+// Queue lengths stay on the device: every launch covers the whole capacity and
+// surplus workgroups leave at once, so a sample runs without host round trips.
+// Draw order of the random numbers and the order of the float sums per pixel
+// are those of the reference's megakernel.
+#include "photon_device.h"
+#include "radix_sort.h"
+#include "shading.h"
+#include "traverse_core.h"
+
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace rt {
+namespace {
+
+constexpr int kShadeBlock = 256;
+
+// Path flags packed beside lastOrigin: bits 0-1 lobe, 2 lastDelta,
+// 3 primaryChain, 4 guidePending, bits 8.. (medium material + 1).
+constexpr uint32_t kLastDelta = 4U, kPrimaryChain = 8U, kGuidePending = 16U;
+
+struct Buffers {
+    uint32_t capacity;
+    float4* rayOrigin[2];
+    float4* rayDirection[2];
+    uint32_t* rayPath[2];   // path (pixel / emission) index of the ray in each slot
+    uint4* hits;
+    uint32_t* hitInstance;
+    float4* shadowOrigin;
+    float4* shadowDirection;
+    float4* shadowContribution;  // xyz + bits: lobe (0-1), needs the light's own triangle (2)
+    uint32_t* shadowPath;
+    uint2* shadowTarget;         // instance, primitive of the sampled emissive triangle
+    uint32_t* rng;
+    float4* throughput;          // xyz + lastPdf (camera) / power xyz (photons)
+    float4* lastOrigin;          // xyz + flags
+    float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
+    uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length
+    unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers
+    rt_photon* photonTemp;       // photon pass: one slot per emission of the batch
+    uint32_t* photonFlags;
+};
+
+// Slots for the lanes with `want` set: a wave ballot, a workgroup prefix and one
+// atomic on *counter per workgroup.  Every thread of the workgroup calls this.
+__device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t* shared /* 8 words */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votes = __ballot(want);
+    if (lane == 0)
+        shared[wave] = __popcll(votes);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kShadeBlock / 64; ++w) {
+            const uint32_t c = shared[w];
+            shared[w] = total;
+            total += c;
+        }
+        shared[4] = total ? atomicAdd(counter, total) : 0U;
+    }
+    __syncthreads();
+    const uint32_t slot = shared[4] + shared[wave] + __popcll(votes & ((1ULL << lane) - 1ULL));
+    __syncthreads();
+    return slot;
+}
+
+// ---- camera paths -----------------------------------------------------------
+
+// device.cu:882-906: one path per pixel of [pixelBegin, pixelBegin + count)
+__global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p, uint32_t pixelBegin, uint32_t count,
+                                                              Buffers b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        b.counts[0] = count;
+        b.counts[1] = 0;
+        b.counts[2] = 0;
+    }
+    if (i >= count)
+        return;
+    const uint32_t index = pixelBegin + i;
+    const uint32_t px = index % p.width, py = index / p.width;
+    uint32_t rng = index * 9781U + p.sample * 6271U + 0x68bc21ebU;
+    const float jx = random01(rng);
+    const float jy = random01(rng);
+    const float sx = (static_cast<float>(px) + jx) / static_cast<float>(p.width);
+    const float sy = (static_cast<float>(py) + jy) / static_cast<float>(p.height);
+    const V3 pinhole = normalize(v3(p.cameraW) + (2.0f * sx - 1.0f) * v3(p.cameraU) + (2.0f * sy - 1.0f) * v3(p.cameraV));
+    const V3 focalPoint = v3(p.eye) + pinhole * (p.focusDistance / fmaxf(dot(pinhole, v3(p.cameraW)), 1e-4f));
+    // lensSample, device.cu:372-377 (drawn even with a closed aperture)
+    const float radius = sqrtf(random01(rng));
+    const float angle = 6.2831853f * random01(rng);
+    const V3 origin = v3(p.eye) + (v3(p.lensU) * (radius * cosf(angle) * p.aperture) +
+                                   v3(p.lensV) * (radius * sinf(angle) * p.aperture));
+    const V3 direction = normalize(focalPoint - origin);
+    b.rayOrigin[0][i] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+    b.rayDirection[0][i] = make_float4(direction.x, direction.y, direction.z, 1e16f);
+    b.rayPath[0][i] = i;
+    b.rng[i] = rng;
+    b.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    b.lastOrigin[i] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kLastDelta | kPrimaryChain | kGuidePending));
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        b.sample[k][i] = zero;
+}
+
+// Closest hit for the first counts[which] rays of a queue (the extend stage).
+__global__ __launch_bounds__(kTraceBlock) void extendKernel(const WideNode* topNodes, const InstanceRecord* instances,
+                                                            Buffers b, int which) {
+    __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
+    __shared__ float stackT[kLdsStack][kTraceBlock];
+    const uint32_t n = b.counts[which];
+    const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+    if (blockIdx.x >= blocks)
+        return;
+    const uint32_t ray = xcdRemap(blockIdx.x, blocks) * kTraceBlock + threadIdx.x;
+    if (ray >= n)
+        return;
+    const float4 o4 = b.rayOrigin[which][ray];
+    const float4 d4 = b.rayDirection[which][ray];
+    TraceCounters unused;
+    const TraceResult r = traceRay<false>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w,
+                                          false, &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x], kTraceBlock, unused);
+    b.hits[ray] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
+    b.hitInstance[ray] = r.instance;
+}
+
+// One bounce of device.cu:908-1041 for every path of queue `which`.
+__global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
+                                                           const rt_hit_group_data* geometries, Buffers b, int which,
+                                                           uint32_t depth) {
+    __shared__ uint32_t slots[8];
+    const uint32_t n = b.counts[which];
+    if (blockIdx.x * kShadeBlock >= n)
+        return;  // whole workgroup idle
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    const bool active = slot < n;
+
+    bool continues = false, wantsShadow = false;
+    V3 origin{0, 0, 0}, direction{0, 0, 0};
+    V3 shadowOrigin{0, 0, 0}, shadowDirection{0, 0, 0}, contribution{0, 0, 0};
+    float shadowLimit = 0.0f;
+    uint32_t shadowBits = 0, targetInstance = 0, targetPrimitive = 0;
+    uint32_t path = 0;
+    uint32_t gathered = 0, gatherQueries = 0;
+
+    if (active) {
+        path = b.rayPath[which][slot];
+        const float4 o4 = b.rayOrigin[which][slot];
+        const float4 d4 = b.rayDirection[which][slot];
+        origin = V3{o4.x, o4.y, o4.z};
+        direction = V3{d4.x, d4.y, d4.z};
+        const uint4 h = b.hits[slot];
+        const float4 tp = b.throughput[path];
+        V3 throughput{tp.x, tp.y, tp.z};
+        float lastPdf = tp.w;
+        const float4 lo = b.lastOrigin[path];
+        const V3 lastOrigin{lo.x, lo.y, lo.z};
+        uint32_t flags = __float_as_uint(lo.w);
+        uint32_t lobe = flags & 3U;
+        bool lastDelta = flags & kLastDelta, primaryChain = flags & kPrimaryChain, guidePending = flags & kGuidePending;
+        int medium = static_cast<int>(flags >> 8) - 1;
+        uint32_t rng = b.rng[path];
+
+        if (h.w == kNoHit) {
+            // device.cu:910-915
+            const float pdf = lastDelta ? 0.0f : environmentDensity(p, direction);
+            const float weight = lastDelta ? 1.0f : powerHeuristic(lastPdf, pdf);
+            const float4 r = b.sample[lobe][path];
+            const V3 sum = rgb(r) + throughput * environmentRadiance(p, direction) * weight;
+            b.sample[lobe][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        } else {
+            rt_hit hit;
+            reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
+                           __uint_as_float(h.z), h.w, b.hitInstance[slot], hit);
+            const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
+            const V3 normal = shadingNormal(p.textures, hit, m);
+            hit.normal = r3(normal);
+            const V3 view = -direction;
+            if (depth == 0U) {
+                // device.cu:920-931
+                lobe = m.transmission > 0.5f ? 2U : m.metallic > 0.5f ? 1U : 0U;
+                b.sample[5][path] = make_float4(dot(normal, v3(p.lensU)), dot(normal, v3(p.lensV)),
+                                                dot(normal, v3(p.cameraW)), 0.0f);
+            }
+            if (guidePending) {
+                // device.cu:932-940
+                const bool clearGlass = m.transmission > 0.95f && m.roughness < 0.1f;
+                if (!clearGlass) {
+                    if (m.transmission < 0.05f)
+                        b.sample[4][path] = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, 0.0f);
+                    guidePending = false;
+                }
+            }
+            if (medium >= 0)
+                throughput = throughput * mediumAbsorption(p.materials[medium], hit.distance);
+            // device.cu:943-947
+            const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, lastOrigin, hit);
+            const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
+            V3 radiance = rgb(b.sample[lobe][path]);
+            radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
+
+            // next event estimation, device.cu:580-605; the visibility query is
+            // deferred to the shadow stage, which adds `contribution` when the
+            // light is seen
+            const float diffuseWeight = (1.0f - m.metallic) * (1.0f - m.transmission);
+            if (diffuseWeight > 0.0f) {
+                const LightDraw light = drawLight(p, v3(hit.position), rng);
+                const float cosine = dot(normal, light.direction);
+                if (light.valid && cosine > 0.0f) {
+                    const V3 reflectance = schlickFresnel(normalReflectance(m), fmaxf(dot(view, normal), 0.0f));
+                    const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
+                    const V3 bsdf = rgb(m.baseColor) * diffuse * (diffuseWeight / 3.14159265f);
+                    const float bsdfPdf = (1.0f - m.transmission) * (1.0f - specularChoice(m, view, normal)) * cosine /
+                                          3.14159265f;
+                    const float weight = light.delta ? 1.0f : powerHeuristic(light.pdf, bsdfPdf);
+                    contribution = throughput * (bsdf * light.radiance * (cosine * weight / light.pdf));
+                    wantsShadow = true;
+                    shadowOrigin = v3(hit.position) + normal * 0.001f;  // device.cu:550-552
+                    shadowDirection = light.direction;
+                    shadowLimit = light.delta ? light.distance - 0.002f : light.distance + 0.002f;
+                    const bool needsTriangle = !light.environment && !light.delta;
+                    shadowBits = lobe | (needsTriangle ? 4U : 0U);
+                    targetInstance = light.instance;
+                    targetPrimitive = light.primitive;
+                }
+            }
+            b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+
+            // caustic gather, device.cu:722-766, 949-950
+            if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
+                float fx, fy, fz;
+                gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, hit.position.x,
+                           hit.position.y, hit.position.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered);
+                gatherQueries = 1;
+                const float radiusSquared = p.photonRadius * p.photonRadius;
+                const float kernel = 2.0f / (3.14159265f * radiusSquared * 3.14159265f);
+                const V3 caustic = rgb(m.baseColor) * (diffuseWeight * kernel) * V3{fx, fy, fz};
+                const V3 sum = rgb(b.sample[3][path]) + throughput * caustic;
+                b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+            }
+
+            // scattering, device.cu:952-1032
+            continues = true;
+            const bool transmissive = m.transmission > 0.0f && random01(rng) < m.transmission;
+            if (transmissive) {
+                lastDelta = true;
+                continues = dielectricEvent(m, hit, rng, origin, direction, throughput, medium);
+            } else {
+                const V3 color = rgb(m.baseColor);
+                const V3 f0 = normalReflectance(m);
+                const float viewCosine = fmaxf(dot(view, normal), 0.0f);
+                const float probability = specularChoice(m, view, normal);
+                if (random01(rng) < probability) {
+                    lastDelta = true;
+                    const float alpha = alphaOf(m.roughness);
+                    const V3 microNormal = sampleVisibleNormal(view, normal, alpha, rng);
+                    direction = reflectAbout(direction, microNormal);
+                    const float lightCosine = dot(direction, normal);
+                    if (lightCosine <= 0.0f)
+                        continues = false;
+                    else
+                        throughput = throughput * (schlickFresnel(f0, fmaxf(dot(view, microNormal), 0.0f)) *
+                                                   (maskingRatio(viewCosine, lightCosine, alpha) / probability));
+                } else {
+                    lastDelta = false;
+                    primaryChain = false;
+                    direction = sampleCosine(normal, rng);
+                    const V3 reflectance = schlickFresnel(f0, viewCosine);
+                    const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
+                    throughput = throughput * (color * diffuse * ((1.0f - m.metallic) / (1.0f - probability)));
+                    lastPdf = (1.0f - m.transmission) * (1.0f - probability) * fmaxf(dot(normal, direction), 0.0f) /
+                              3.14159265f;
+                }
+                origin = v3(hit.position) + normal * 0.001f;
+            }
+            // Russian roulette, device.cu:1035-1040
+            if (continues && depth > 2U) {
+                const float survival = fminf(fmaxf(maximum(throughput), 0.05f), 0.95f);
+                if (random01(rng) > survival)
+                    continues = false;
+                else
+                    throughput = throughput / survival;
+            }
+            if (depth + 1U >= p.maxDepth)
+                continues = false;
+            if (continues) {
+                b.rng[path] = rng;
+                b.throughput[path] = make_float4(throughput.x, throughput.y, throughput.z, lastPdf);
+                flags = lobe | (lastDelta ? kLastDelta : 0U) | (primaryChain ? kPrimaryChain : 0U) |
+                        (guidePending ? kGuidePending : 0U) | static_cast<uint32_t>(medium + 1) << 8;
+                b.lastOrigin[path] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(flags));
+            }
+        }
+    }
+
+    const int next = which ^ 1;
+    const uint32_t nextSlot = allocateSlots(continues, &b.counts[next], slots);
+    if (continues) {
+        b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+        b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
+        b.rayPath[next][nextSlot] = path;
+    }
+    const uint32_t shadowSlot = allocateSlots(wantsShadow, &b.counts[2], slots);
+    if (wantsShadow) {
+        b.shadowOrigin[shadowSlot] = make_float4(shadowOrigin.x, shadowOrigin.y, shadowOrigin.z, 0.001f);
+        b.shadowDirection[shadowSlot] = make_float4(shadowDirection.x, shadowDirection.y, shadowDirection.z, shadowLimit);
+        b.shadowContribution[shadowSlot] =
+            make_float4(contribution.x, contribution.y, contribution.z, __uint_as_float(shadowBits));
+        b.shadowPath[shadowSlot] = path;
+        b.shadowTarget[shadowSlot] = make_uint2(targetInstance, targetPrimitive);
+    }
+    // gather statistics: one atomic pair per wave
+    unsigned long long q = gatherQueries, g = gathered;
+#pragma unroll
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+        q += __shfl_down(q, delta, 64);
+        g += __shfl_down(g, delta, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && q) {
+        atomicAdd(&b.stats[2], q);
+        atomicAdd(&b.stats[3], g);
+    }
+}
+
+// visible(), device.cu:548-559: the light is seen when nothing is hit before
+// it (delta lights, environment) or when the closest hit is the sampled
+// emissive triangle itself; then the deferred contribution is added.
+__global__ __launch_bounds__(kTraceBlock) void shadowKernel(const WideNode* topNodes, const InstanceRecord* instances,
+                                                            Buffers b) {
+    __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
+    __shared__ float stackT[kLdsStack][kTraceBlock];
+    const uint32_t n = b.counts[2];
+    const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+    if (blockIdx.x >= blocks)
+        return;
+    const uint32_t ray = xcdRemap(blockIdx.x, blocks) * kTraceBlock + threadIdx.x;
+    if (ray >= n)
+        return;
+    const float4 o4 = b.shadowOrigin[ray];
+    const float4 d4 = b.shadowDirection[ray];
+    const float4 c4 = b.shadowContribution[ray];
+    const uint32_t bits = __float_as_uint(c4.w);
+    const bool needsTriangle = bits & 4U;
+    TraceCounters unused;
+    const TraceResult r = traceRay<false>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w,
+                                          !needsTriangle, &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x],
+                                          kTraceBlock, unused);
+    const bool found = r.primitive != kNoHit;
+    bool seen;
+    if (needsTriangle) {
+        const uint2 target = b.shadowTarget[ray];
+        seen = found && r.instance == target.x && r.primitive == target.y;
+    } else {
+        seen = !found;
+    }
+    if (seen) {
+        const uint32_t path = b.shadowPath[ray];
+        const uint32_t lobe = bits & 3U;
+        const float4 acc = b.sample[lobe][path];
+        b.sample[lobe][path] = make_float4(acc.x + c4.x, acc.y + c4.y, acc.z + c4.z, 0.0f);
+    }
+}
+
+// Bookkeeping between bounces: ray statistics, then the consumed queues are emptied.
+__global__ void advanceKernel(Buffers b, int which) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        b.stats[0] += b.counts[which];
+        b.stats[1] += b.counts[2];
+        b.counts[which] = 0;
+        b.counts[2] = 0;
+    }
+}
+
+// device.cu:1043-1074: running means of the seven buffers and the tone-mapped byte image.
+__global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params p, uint32_t pixelBegin,
+                                                                uint32_t count, Buffers b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint32_t index = pixelBegin + i;
+    const float weight = 1.0f / static_cast<float>(p.sample + 1U);
+    const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
+    const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
+    const V3 sample = r0 + r1 + r2 + caustic;
+    auto blend = [&](rt_float4* buffer, V3 value) {
+        const V3 previous = rgb(buffer[index]);
+        const V3 next = previous + (value - previous) * weight;
+        rt_float4 out;
+        out.x = next.x;
+        out.y = next.y;
+        out.z = next.z;
+        out.w = 1.0f;
+        buffer[index] = out;
+        return next;
+    };
+    const V3 accumulated = blend(p.accumulation, sample);
+    blend(p.diffuse, r0);
+    blend(p.reflection, r1);
+    blend(p.refraction, r2);
+    blend(p.caustics, caustic);
+    blend(p.albedoGuide, albedo);
+    blend(p.normalGuide, normal);
+    if (p.output) {
+        const V3 mapped = acesTonemap(accumulated * exp2f(p.exposure));
+        rt_uchar4 out;
+        out.x = static_cast<unsigned char>(mapped.x * 255.0f + 0.5f);
+        out.y = static_cast<unsigned char>(mapped.y * 255.0f + 0.5f);
+        out.z = static_cast<unsigned char>(mapped.z * 255.0f + 0.5f);
+        out.w = 255;
+        p.output[index] = out;
+    }
+}
+
+// ---- photon pass --------------------------------------------------------------
+
+// emitPhoton, device.cu:652-712, for emissions [first, first + count)
+__global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_params p, uint32_t first, uint32_t count,
+                                                                    Buffers b) {
+    __shared__ uint32_t slots[8];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    V3 origin{0, 0, 0}, direction{0, 0, 0}, power{0, 0, 0};
+    uint32_t rng = 0;
+    if (i < count) {
+        b.photonFlags[i] = 0;
+        rng = seeded(first + i, p.photonPass);
+        float choice = 0.0f;
+        const rt_gpu_light* selected = pickLight(p, rng, choice);
+        if (selected) {
+            const rt_gpu_light light = *selected;
+            const float normalization = 1.0f / (static_cast<float>(p.photonEmissions) * choice);
+            const V3 center = v3(p.sceneCenter);
+            const float sceneRadius = p.sceneRadius;
+            if (light.type == 4U) {
+                const EnvironmentDraw source = drawEnvironment(p, rng);
+                direction = -source.direction;
+                origin = center - direction * sceneRadius + sampleDisk(direction, sceneRadius, rng);
+                power = source.radiance * (3.14159265f * sceneRadius * sceneRadius * normalization / source.pdf);
+            } else if (light.type == 3U) {
+                const float root = sqrtf(random01(rng));
+                const float u = 1.0f - root;
+                const float v = random01(rng) * root;
+                origin = v3(light.a) * u + v3(light.b) * v + v3(light.c) * (1.0f - u - v);
+                const V3 side = random01(rng) < 0.5f ? v3(light.normal) : -v3(light.normal);
+                direction = sampleCosine(side, rng);
+                origin = origin + direction * 0.001f;
+                power = v3(light.emission) * (6.2831853f * light.area * normalization);
+            } else if (light.type == 0U) {
+                direction = normalize(v3(light.b));
+                origin = center - direction * sceneRadius + sampleDisk(direction, sceneRadius, rng);
+                power = v3(light.emission) * (3.14159265f * sceneRadius * sceneRadius * normalization);
+            } else {
+                origin = v3(light.a);
+                if (light.type == 1U) {
+                    const float outer = cosf(light.outerCone);
+                    const float cosine = 1.0f - random01(rng) * (1.0f - outer);
+                    direction = sampleAround(normalize(v3(light.b)), cosine, rng);
+                    const float inner = cosf(light.innerCone);
+                    const float falloff = saturate((cosine - outer) / fmaxf(inner - outer, 1e-5f));
+                    power = v3(light.emission) * (6.2831853f * (1.0f - outer) * falloff * falloff * normalization);
+                } else {
+                    const float cosine = 1.0f - 2.0f * random01(rng);
+                    direction = sampleAround(V3{0.0f, 1.0f, 0.0f}, cosine, rng);
+                    power = v3(light.emission) * (12.566371f * normalization);
+                }
+                origin = origin + direction * 0.001f;
+            }
+            valid = maximum(power) > 0.0f;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        b.counts[1] = 0;
+        b.counts[2] = 0;
+    }
+    const uint32_t slot = allocateSlots(valid, &b.counts[0], slots);
+    if (valid) {
+        b.rayOrigin[0][slot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+        b.rayDirection[0][slot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
+        b.rayPath[0][slot] = i;
+        b.rng[i] = rng;
+        b.throughput[i] = make_float4(power.x, power.y, power.z, 0.0f);
+        b.lastOrigin[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0U));  // flags: bit 0 specular path, medium
+    }
+}
+
+// One bounce of device.cu:782-860 for every photon of queue `which`.
+__global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_params p, const ShadeInstance* instances,
+                                                                 const rt_hit_group_data* geometries, Buffers b,
+                                                                 int which, uint32_t depth) {
+    __shared__ uint32_t slots[8];
+    const uint32_t n = b.counts[which];
+    if (blockIdx.x * kShadeBlock >= n)
+        return;
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
+    bool continues = false;
+    V3 origin{0, 0, 0}, direction{0, 0, 0};
+    uint32_t path = 0;
+    if (slot < n) {
+        path = b.rayPath[which][slot];
+        const uint4 h = b.hits[slot];
+        if (h.w != kNoHit) {
+            const float4 o4 = b.rayOrigin[which][slot];
+            const float4 d4 = b.rayDirection[which][slot];
+            origin = V3{o4.x, o4.y, o4.z};
+            direction = V3{d4.x, d4.y, d4.z};
+            const float4 pw = b.throughput[path];
+            V3 power{pw.x, pw.y, pw.z};
+            uint32_t flags = __float_as_uint(b.lastOrigin[path].w);
+            bool specularPath = flags & 1U;
+            int medium = static_cast<int>(flags >> 8) - 1;
+            uint32_t rng = b.rng[path];
+            rt_hit hit;
+            reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
+                           __uint_as_float(h.z), h.w, b.hitInstance[slot], hit);
+            const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
+            const V3 normal = shadingNormal(p.textures, hit, m);
+            hit.normal = r3(normal);
+            if (medium >= 0)
+                power = power * mediumAbsorption(p.materials[medium], hit.distance);
+            const float diffuseWeight = (1.0f - m.metallic) * (1.0f - m.transmission);
+            if (specularPath && diffuseWeight > 0.0f) {
+                // storePhoton, device.cu:714-720; its slot is decided after the batch, in emission order
+                rt_photon photon;
+                photon.position = hit.position;
+                photon.power = r3(power);
+                photon.normal = hit.normal;
+                b.photonTemp[path] = photon;
+                b.photonFlags[path] = 1;
+            } else if (m.transmission > 0.0f && random01(rng) < m.transmission) {
+                continues = dielectricEvent(m, hit, rng, origin, direction, power, medium);
+                specularPath = true;
+            } else if (m.metallic > 0.5f && m.roughness < 0.3f) {
+                // device.cu:843-858
+                const V3 view = -direction;
+                const float alpha = alphaOf(m.roughness);
+                const V3 microNormal = sampleVisibleNormal(view, normal, alpha, rng);
+                const V3 reflected = reflectAbout(direction, microNormal);
+                const float lightCosine = dot(reflected, normal);
+                if (lightCosine > 0.0f) {
+                    power = power * (schlickFresnel(normalReflectance(m), fmaxf(dot(view, microNormal), 0.0f)) *
+                                     maskingRatio(fabsf(dot(view, normal)), lightCosine, alpha));
+                    direction = reflected;
+                    origin = v3(hit.position) + normal * 0.001f;
+                    specularPath = true;
+                    continues = true;
+                }
+            }
+            if (depth + 1U >= 10U)
+                continues = false;
+            if (continues) {
+                b.rng[path] = rng;
+                b.throughput[path] = make_float4(power.x, power.y, power.z, 0.0f);
+                flags = (specularPath ? 1U : 0U) | static_cast<uint32_t>(medium + 1) << 8;
+                b.lastOrigin[path] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
+            }
+        }
+    }
+    const int next = which ^ 1;
+    const uint32_t nextSlot = allocateSlots(continues, &b.counts[next], slots);
+    if (continues) {
+        b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+        b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
+        b.rayPath[next][nextSlot] = path;
+    }
+}
+
+// Appends the batch's stored photons behind *photonCount in emission order
+// (offsets = exclusive scan of the flags; offsets[count] = photons of the batch).
+__global__ __launch_bounds__(256) void photonCompactKernel(rt_launch_params p, uint32_t count, const uint32_t* offsets,
+                                                           Buffers b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    if (offsets[i + 1] != offsets[i]) {
+        const uint32_t slot = *p.photonCount + offsets[i];
+        if (slot < p.photonCapacity)
+            p.photons[slot] = b.photonTemp[i];
+    }
+}
+
+__global__ void photonCountKernel(rt_launch_params p, uint32_t count, const uint32_t* offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        *p.photonCount += offsets[count];
+}
+
+}  // namespace
+}  // namespace rt
+
+struct rt_wavefront {
+    int device = 0;
+    rt::Buffers buffers{};
+    std::vector<void*> allocations;
+    uint32_t* scanCounts = nullptr;    // capacity + 1
+    uint32_t* scanPartials = nullptr;
+};
+
+using namespace rt;
+
+extern "C" {
+
+void rt_wavefront_destroy(rt_wavefront* w) {
+    if (!w)
+        return;
+    for (void* p : w->allocations)
+        (void)hipFree(p);
+    delete w;
+}
+
+rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
+    if (!out)
+        return failInvalid("out is null");
+    *out = nullptr;
+    if (maxPaths == 0)
+        return failInvalid("maxPaths is zero");
+    auto* w = new rt_wavefront();
+    RT_HIP(hipGetDevice(&w->device));
+    rt_status status = RT_SUCCESS;
+    auto allocate = [&](auto*& pointer, size_t count) {
+        using T = std::remove_reference_t<decltype(*pointer)>;
+        void* raw = nullptr;
+        if (status != RT_SUCCESS)
+            return;
+        const hipError_t e = hipMalloc(&raw, sizeof(T) * count);
+        if (e != hipSuccess) {
+            status = fail(e, "hipMalloc (wavefront buffers)");
+            return;
+        }
+        w->allocations.push_back(raw);
+        pointer = static_cast<T*>(raw);
+    };
+    Buffers& b = w->buffers;
+    b.capacity = maxPaths;
+    for (int k = 0; k < 2; ++k) {
+        allocate(b.rayOrigin[k], maxPaths);
+        allocate(b.rayDirection[k], maxPaths);
+        allocate(b.rayPath[k], maxPaths);
+    }
+    allocate(b.hits, maxPaths);
+    allocate(b.hitInstance, maxPaths);
+    allocate(b.shadowOrigin, maxPaths);
+    allocate(b.shadowDirection, maxPaths);
+    allocate(b.shadowContribution, maxPaths);
+    allocate(b.shadowPath, maxPaths);
+    allocate(b.shadowTarget, maxPaths);
+    allocate(b.rng, maxPaths);
+    allocate(b.throughput, maxPaths);
+    allocate(b.lastOrigin, maxPaths);
+    for (int k = 0; k < 6; ++k)
+        allocate(b.sample[k], maxPaths);
+    allocate(b.counts, 4);
+    allocate(b.stats, 4);
+    allocate(b.photonTemp, maxPaths);
+    allocate(b.photonFlags, static_cast<size_t>(maxPaths) + 1);
+    allocate(w->scanCounts, static_cast<size_t>(maxPaths) + 1);
+    allocate(w->scanPartials, scanScratchEntries(static_cast<size_t>(maxPaths) + 1));
+    if (status == RT_SUCCESS) {
+        if (hipMemset(b.counts, 0, sizeof(uint32_t) * 4) != hipSuccess ||
+            hipMemset(b.stats, 0, sizeof(unsigned long long) * 4) != hipSuccess)
+            status = failInvalid("hipMemset (wavefront counters)");
+    }
+    if (status != RT_SUCCESS) {
+        rt_wavefront_destroy(w);
+        return status;
+    }
+    *out = w;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_stats(rt_wavefront* w, uint64_t* out4, int reset, void* stream) {
+    if (!w || !out4)
+        return failInvalid("null pointer");
+    auto s = static_cast<hipStream_t>(stream);
+    RT_HIP(hipMemcpyAsync(out4, w->buffers.stats, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipStreamSynchronize(s));
+    if (reset)
+        RT_HIP(hipMemsetAsync(w->buffers.stats, 0, sizeof(uint64_t) * 4, s));
+    return RT_SUCCESS;
+}
+
+static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
+    if (!w || !params)
+        return failInvalid("null pointer");
+    scene = reinterpret_cast<const rt_scene*>(params->scene);
+    if (!scene)
+        return failInvalid("launch parameters carry no scene handle");
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
+    if (device != w->device || device != scene->device)
+        return failInvalid("wavefront state or scene lives on another device");
+    if (!scene->hitGroups || !scene->shadeInstances)
+        return failInvalid("rt_scene_set_geometry has not been called");
+    if (!params->materials)
+        return failInvalid("launch parameters carry no materials");
+    return RT_SUCCESS;
+}
+
+rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin, uint32_t pixelEnd,
+                           void* stream) {
+    const rt_scene* scene = nullptr;
+    RT_TRY(checkLaunch(w, params, scene));
+    if (pixelEnd < pixelBegin || pixelEnd > params->width * params->height)
+        return failInvalid("pixel range");
+    const uint32_t count = pixelEnd - pixelBegin;
+    if (count == 0)
+        return RT_SUCCESS;
+    if (count > w->buffers.capacity)
+        return failInvalid("pixel range larger than the wavefront capacity");
+    auto s = static_cast<hipStream_t>(stream);
+    const Buffers& b = w->buffers;
+    const unsigned blocks = divUp(count, kShadeBlock);
+    hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+    for (uint32_t depth = 0; depth < params->maxDepth; ++depth) {
+        const int which = depth & 1U;
+        hipLaunchKernelGGL(extendKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b, which);
+        hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
+                           scene->hitGroups, b, which, depth);
+        hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b);
+        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
+    }
+    hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint32_t firstEmission,
+                           uint32_t emissionCount, void* stream) {
+    const rt_scene* scene = nullptr;
+    RT_TRY(checkLaunch(w, params, scene));
+    if (!params->photons || !params->photonCount)
+        return failInvalid("launch parameters carry no photon buffers");
+    auto s = static_cast<hipStream_t>(stream);
+    const Buffers& b = w->buffers;
+    uint32_t done = 0;
+    while (done < emissionCount) {
+        const uint32_t count = std::min(b.capacity, emissionCount - done);
+        const unsigned blocks = divUp(count, kShadeBlock);
+        RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 4, s));
+        hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, firstEmission + done,
+                           count, b);
+        for (uint32_t depth = 0; depth < 10U; ++depth) {
+            const int which = depth & 1U;
+            hipLaunchKernelGGL(extendKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b,
+                               which);
+            hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
+                               scene->hitGroups, b, which, depth);
+            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
+        }
+        // emission-ordered append: offsets = exclusive scan of the flags (with a
+        // trailing zero so that offsets[count] is the batch total)
+        RT_HIP(hipMemsetAsync(b.photonFlags + count, 0, sizeof(uint32_t), s));
+        RT_TRY(exclusiveScanU32(b.photonFlags, w->scanCounts, static_cast<size_t>(count) + 1, w->scanPartials, s));
+        hipLaunchKernelGGL(photonCompactKernel, dim3(divUp(count, 256)), dim3(256), 0, s, *params, count,
+                           w->scanCounts, b);
+        hipLaunchKernelGGL(photonCountKernel, dim3(1), dim3(64), 0, s, *params, count, w->scanCounts);
+        RT_HIP(hipGetLastError());
+        done += count;
+    }
+    return RT_SUCCESS;
+}
+
+}  // extern "C"

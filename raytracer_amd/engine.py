@@ -60,6 +60,13 @@ SYMBOLS = {
     "rt_trace_closest": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rt_trace_any": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "rt_trace_closest_counted": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "rt_photon_gather_counted": (C.c_int, [_vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "rt_scene_set_geometry": (C.c_int, [_vp, _vp, _u32]),
+    "rt_wavefront_create": (C.c_int, [_u32, C.POINTER(_vp)]),
+    "rt_wavefront_destroy": (None, [_vp]),
+    "rt_render_sample": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "rt_trace_photons": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "rt_wavefront_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
 }
 
 _lib = None
@@ -150,15 +157,21 @@ class PhotonGrid:
         self.count = n
         self.cell_size = float(cell_size)
 
-    def gather(self, qpos, qnormal, radius=None, stream=None, out=None):
+    def gather(self, qpos, qnormal, radius=None, stream=None, out=None, visited=None):
+        """visited: optional (1,) int64 device tensor that receives the number of photons read."""
         import torch
         assert qpos.is_cuda and qpos.dtype == torch.float32 and qpos.is_contiguous()
         assert qnormal.is_cuda and qnormal.dtype == torch.float32 and qnormal.is_contiguous()
         n = qpos.shape[0]
         flux = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=qpos.device)
-        check(load().rt_photon_gather(_ptr(self.sorted), _ptr(self.offsets), self.bucket_count,
-                                      float(self.cell_size if radius is None else radius), _ptr(qpos), _ptr(qnormal),
-                                      n, _ptr(flux), _stream(stream)))
+        r = float(self.cell_size if radius is None else radius)
+        if visited is None:
+            check(load().rt_photon_gather(_ptr(self.sorted), _ptr(self.offsets), self.bucket_count, r, _ptr(qpos),
+                                          _ptr(qnormal), n, _ptr(flux), _stream(stream)))
+        else:
+            check(load().rt_photon_gather_counted(_ptr(self.sorted), _ptr(self.offsets), self.bucket_count, r,
+                                                  _ptr(qpos), _ptr(qnormal), n, _ptr(flux), _ptr(visited),
+                                                  _stream(stream)))
         return flux
 
 

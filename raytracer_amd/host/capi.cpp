@@ -1,0 +1,226 @@
+// C binding of the host layer (rt::Scene + rt::Renderer) for callers that cannot
+// use the C++ classes directly: the Python mirror, the tests and the benchmark.
+// Exceptions become a non-zero return and a message (rth_last_error()).
+#include "renderer.hpp"
+
+#include "rt_types.h"
+
+#include <cstring>
+#include <exception>
+#include <string>
+
+namespace {
+
+thread_local std::string lastError;
+
+template <typename F>
+int guarded(F&& body) {
+    try {
+        body();
+        return 0;
+    } catch (const std::exception& e) {
+        lastError = e.what();
+        return 1;
+    }
+}
+
+rt::Mat4 matrix(const float* m16) {
+    rt::Mat4 m;
+    std::memcpy(m.values.data(), m16, sizeof(float) * 16);
+    return m;
+}
+
+rt::TextureRef textureRef(const rt_gpu_texture_ref& r) {
+    rt::TextureRef t;
+    t.texture = r.texture;
+    t.texCoord = r.texCoord;
+    t.offset = {r.offset.x, r.offset.y};
+    t.scale = {r.scale.x, r.scale.y};
+    t.rotation = r.rotation;
+    t.strength = r.strength;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rth_last_error(void) { return lastError.c_str(); }
+
+rt::Scene* rth_scene_create(void) { return new rt::Scene(); }
+void rth_scene_destroy(rt::Scene* scene) { delete scene; }
+
+// Material fields as laid out in rt_gpu_material (the scene.hpp:52-73 members).
+int rth_scene_add_material(rt::Scene* scene, const rt_gpu_material* m) {
+    rt::Material out;
+    out.baseColor = {m->baseColor.x, m->baseColor.y, m->baseColor.z, m->baseColor.w};
+    out.emissive = {m->emissive.x, m->emissive.y, m->emissive.z};
+    out.attenuationColor = {m->attenuationColor.x, m->attenuationColor.y, m->attenuationColor.z};
+    out.metallic = m->metallic;
+    out.roughness = m->roughness;
+    out.transmission = m->transmission;
+    out.ior = m->ior;
+    out.thickness = m->thickness;
+    out.attenuationDistance = m->attenuationDistance;
+    out.emissiveStrength = m->emissiveStrength;
+    out.dispersion = m->dispersion;
+    out.baseColorTexture = textureRef(m->baseColorTexture);
+    out.metallicRoughnessTexture = textureRef(m->metallicRoughnessTexture);
+    out.normalTexture = textureRef(m->normalTexture);
+    out.emissiveTexture = textureRef(m->emissiveTexture);
+    out.transmissionTexture = textureRef(m->transmissionTexture);
+    out.thicknessTexture = textureRef(m->thicknessTexture);
+    scene->materials.push_back(out);
+    return static_cast<int>(scene->materials.size()) - 1;
+}
+
+int rth_scene_add_geometry(rt::Scene* scene, const rt_gpu_vertex* vertices, uint32_t vertexCount,
+                           const uint32_t* indices, uint32_t triangleCount, uint32_t material) {
+    rt::Geometry g;
+    g.vertices.resize(vertexCount);
+    for (uint32_t i = 0; i < vertexCount; ++i) {
+        const rt_gpu_vertex& v = vertices[i];
+        g.vertices[i] = {{v.position.x, v.position.y, v.position.z},
+                         {v.normal.x, v.normal.y, v.normal.z},
+                         {v.tangent.x, v.tangent.y, v.tangent.z, v.tangent.w},
+                         {v.uv.x, v.uv.y},
+                         {v.uv1.x, v.uv1.y}};
+    }
+    g.indices.assign(indices, indices + 3 * static_cast<size_t>(triangleCount));
+    g.material = material;
+    scene->geometries.push_back(std::move(g));
+    return static_cast<int>(scene->geometries.size()) - 1;
+}
+
+int rth_scene_add_instance(rt::Scene* scene, uint32_t geometry, const float* m16) {
+    scene->instances.push_back({"", matrix(m16), geometry});
+    return static_cast<int>(scene->instances.size()) - 1;
+}
+
+int rth_scene_add_camera(rt::Scene* scene, const float* m16, float verticalFov, float aspectRatio, float nearPlane,
+                         float aperture, float focusDistance) {
+    rt::Camera c;
+    c.transform = matrix(m16);
+    c.verticalFov = verticalFov;
+    c.aspectRatio = aspectRatio;
+    c.nearPlane = nearPlane;
+    c.aperture = aperture;
+    c.focusDistance = focusDistance;
+    scene->cameras.push_back(c);
+    return static_cast<int>(scene->cameras.size()) - 1;
+}
+
+int rth_scene_add_light(rt::Scene* scene, const float* m16, const float* color3, float intensity, float range,
+                        float innerCone, float outerCone, uint32_t type) {
+    rt::Light l;
+    l.transform = matrix(m16);
+    l.color = {color3[0], color3[1], color3[2]};
+    l.intensity = intensity;
+    l.range = range;
+    l.innerCone = innerCone;
+    l.outerCone = outerCone;
+    l.type = type;
+    scene->lights.push_back(l);
+    return static_cast<int>(scene->lights.size()) - 1;
+}
+
+int rth_scene_add_image(rt::Scene* scene, const uint8_t* rgba, uint32_t width, uint32_t height) {
+    rt::Image image;
+    image.rgba.assign(rgba, rgba + static_cast<size_t>(width) * height * 4);
+    image.width = width;
+    image.height = height;
+    scene->images.push_back(std::move(image));
+    return static_cast<int>(scene->images.size()) - 1;
+}
+
+int rth_scene_add_texture(rt::Scene* scene, int32_t image, uint32_t wrapU, uint32_t wrapV) {
+    rt::Texture t;
+    t.image = image;
+    t.wrapU = wrapU;
+    t.wrapV = wrapV;
+    scene->textures.push_back(t);
+    return static_cast<int>(scene->textures.size()) - 1;
+}
+
+void rth_scene_set_environment(rt::Scene* scene, const float* rgba, uint32_t width, uint32_t height, float rotation,
+                               float strength, float exposure) {
+    auto& e = scene->environment;
+    e.pixels.resize(static_cast<size_t>(width) * height);
+    for (size_t i = 0; i < e.pixels.size(); ++i)
+        e.pixels[i] = {rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]};
+    e.width = width;
+    e.height = height;
+    e.rotation = rotation;
+    e.strength = strength;
+    e.exposure = exposure;
+}
+
+rt::Renderer* rth_renderer_create(const rt::Scene* scene, uint32_t width, uint32_t height, int finalProfile) {
+    rt::Renderer* renderer = nullptr;
+    guarded([&] {
+        renderer = new rt::Renderer(*scene, width, height, finalProfile ? rt::Profile::Final : rt::Profile::Preview);
+    });
+    return renderer;
+}
+
+void rth_renderer_destroy(rt::Renderer* r) { delete r; }
+int rth_renderer_render(rt::Renderer* r, void* output) { return guarded([&] { r->render(output); }); }
+int rth_renderer_denoise(rt::Renderer* r) { return guarded([&] { r->denoise(); }); }
+int rth_renderer_set_camera(rt::Renderer* r, const float* m16, float verticalFov, float aspectRatio, float nearPlane,
+                            float aperture, float focusDistance) {
+    rt::Camera c;
+    c.transform = matrix(m16);
+    c.verticalFov = verticalFov;
+    c.aspectRatio = aspectRatio;
+    c.nearPlane = nearPlane;
+    c.aperture = aperture;
+    c.focusDistance = focusDistance;
+    return guarded([&] { r->setCamera(c); });
+}
+int rth_renderer_set_profile(rt::Renderer* r, int finalProfile) {
+    return guarded([&] { r->setProfile(finalProfile ? rt::Profile::Final : rt::Profile::Preview); });
+}
+int rth_renderer_copy_output(rt::Renderer* r, void* deviceOutput) { return guarded([&] { r->copyOutput(deviceOutput); }); }
+int rth_renderer_pixels(rt::Renderer* r, uint8_t* out) {
+    return guarded([&] {
+        const auto p = r->pixels();
+        std::memcpy(out, p.data(), p.size());
+    });
+}
+int rth_renderer_linear_pixels(rt::Renderer* r, float* out) {
+    return guarded([&] {
+        const auto p = r->linearPixels();
+        std::memcpy(out, p.data(), p.size() * sizeof(float));
+    });
+}
+uint32_t rth_renderer_samples(rt::Renderer* r) { return r->samples(); }
+
+int rth_renderer_set_photon_budget(rt::Renderer* r, uint32_t emissions, uint32_t capacity, uint32_t buckets) {
+    return guarded([&] { r->setPhotonBudget(emissions, capacity, buckets); });
+}
+int rth_renderer_set_pixel_range(rt::Renderer* r, uint32_t begin, uint32_t end) {
+    return guarded([&] { r->setPixelRange(begin, end); });
+}
+void rth_renderer_set_manual_photon_passes(rt::Renderer* r, int manual) { r->setManualPhotonPasses(manual != 0); }
+int rth_renderer_photon_pass_due(rt::Renderer* r) { return r->photonPassDue() ? 1 : 0; }
+int rth_renderer_begin_photon_pass(rt::Renderer* r) { return guarded([&] { r->beginPhotonPass(); }); }
+int rth_renderer_trace_photon_range(rt::Renderer* r, uint32_t first, uint32_t count, uint32_t* stored) {
+    return guarded([&] { *stored = r->tracePhotonRange(first, count); });
+}
+void* rth_renderer_photon_buffer(rt::Renderer* r) { return r->photonBuffer(); }
+uint32_t rth_renderer_photon_capacity(rt::Renderer* r) { return r->photonCapacity(); }
+uint32_t rth_renderer_photon_emissions(rt::Renderer* r) { return r->photonEmissions(); }
+int rth_renderer_finish_photon_pass(rt::Renderer* r, uint32_t total) {
+    return guarded([&] { r->finishPhotonPass(total); });
+}
+void* rth_renderer_accumulation_buffer(rt::Renderer* r, int index) {
+    void* p = nullptr;
+    guarded([&] { p = r->accumulationBuffer(index); });
+    return p;
+}
+int rth_renderer_statistics(rt::Renderer* r, uint64_t* out4) { return guarded([&] { r->statistics(out4); }); }
+int rth_renderer_synchronize(rt::Renderer* r) { return guarded([&] { r->synchronize(); }); }
+void rth_renderer_launch_params(rt::Renderer* r, rt_launch_params* out) { *out = r->launchParams(); }
+float rth_renderer_caustic_radius(rt::Renderer* r) { return r->causticRadius(); }
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// rt::Renderer over the MI355X engine: the public interface of the reference's
+// src/renderer.hpp:11-37 (same constructor, methods, defaults and ownership
+// rules), plus the hooks a multi-GPU driver needs to shard one frame.
+#pragma once
+
+#include "scene.hpp"
+
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+struct rt_launch_params;
+
+namespace rt {
+
+enum class Profile {
+    Preview,  // 5 bounces, no photon map
+    Final     // 32 bounces, caustic photon map rebuilt every 4 samples
+};
+
+class Renderer {
+public:
+    Renderer(const Scene& scene, std::uint32_t width, std::uint32_t height, Profile profile = Profile::Preview);
+    ~Renderer();
+
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    // One more sample for every pixel (of the pixel range).  `output`, when not
+    // null, is a caller-owned DEVICE buffer of width * height RGBA8 pixels.
+    // Returns before the GPU has finished.
+    void render(void* output = nullptr);
+    // The reference runs the OptiX AOV denoiser here; this engine has none and
+    // throws std::runtime_error.
+    void denoise();
+    void setCamera(const Camera& camera);
+    void setProfile(Profile profile);
+    void copyOutput(void* output) const;        // device-to-device
+    std::vector<std::uint8_t> pixels() const;   // RGBA8, row 0 = bottom
+    std::vector<float> linearPixels() const;    // RGBA float32 running mean
+    std::uint32_t samples() const;
+
+    // ---- hooks that are not part of the reference ----------------------------
+    // Photon map sizes (the reference hard-codes 2^24 emissions, 2^23 stored,
+    // 2^22 buckets, src/renderer.cpp:533-535).  Resets the accumulation.
+    void setPhotonBudget(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets);
+    // Restricts render() to the pixels [begin, end) in row-major order.
+    void setPixelRange(std::uint32_t begin, std::uint32_t end);
+    // Splits a photon pass: render() then no longer runs it by itself; the
+    // driver calls beginPhotonPass(), tracePhotonRange() for its share, places
+    // the other ranks' photons behind its own in photonBuffer() and calls
+    // finishPhotonPass() with the total.
+    void setManualPhotonPasses(bool manual);
+    bool photonPassDue() const;
+    void beginPhotonPass();
+    std::uint32_t tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount);  // returns stored count
+    void* photonBuffer() const;           // device, photonCapacity() * 36 bytes
+    std::uint32_t photonCapacity() const;
+    std::uint32_t photonEmissions() const;
+    void finishPhotonPass(std::uint32_t totalPhotons);
+    void* accumulationBuffer(int index) const;  // device float4 buffers: 0 accumulation .. 6 normal guide
+    // Counters since the last call: [0] extend rays, [1] shadow rays, [2] gather
+    // queries, [3] photons read by gathers.  Waits for the GPU.
+    void statistics(std::uint64_t out[4]);
+    void synchronize() const;
+    const rt_launch_params& launchParams() const;
+    float causticRadius() const;
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace rt

@@ -1,0 +1,322 @@
+"""Python mirror of the host layer: rt::Renderer (raytracer_amd/host/renderer.hpp) bound through
+librt_host.so.  Same methods as the reference's src/renderer.hpp:16-37, built from the scene dicts of
+raytracer_amd.workloads.  No CPU fallback: loading fails loudly when the libraries are missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import engine
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "librt_host.so")
+
+PREVIEW, FINAL = 0, 1
+
+
+class Float2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class Float3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class GpuTextureRef(C.Structure):
+    _fields_ = [("texture", C.c_int32), ("texCoord", C.c_uint32), ("offset", Float2), ("scale", Float2),
+                ("rotation", C.c_float), ("strength", C.c_float)]
+
+
+class GpuMaterial(C.Structure):
+    _fields_ = [("baseColor", Float4), ("emissive", Float3), ("attenuationColor", Float3), ("metallic", C.c_float),
+                ("roughness", C.c_float), ("transmission", C.c_float), ("ior", C.c_float), ("thickness", C.c_float),
+                ("attenuationDistance", C.c_float), ("emissiveStrength", C.c_float), ("dispersion", C.c_float),
+                ("baseColorTexture", GpuTextureRef), ("metallicRoughnessTexture", GpuTextureRef),
+                ("normalTexture", GpuTextureRef), ("emissiveTexture", GpuTextureRef),
+                ("transmissionTexture", GpuTextureRef), ("thicknessTexture", GpuTextureRef),
+                ("_tail", C.c_uint8 * 8)]  # the C struct is 16-byte aligned (float4 member)
+
+
+class GpuTexture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("wrapU", C.c_uint32),
+                ("wrapV", C.c_uint32)]
+
+
+class GpuLight(C.Structure):
+    _fields_ = [("a", Float3), ("b", Float3), ("c", Float3), ("normal", Float3), ("emission", Float3),
+                ("area", C.c_float), ("weight", C.c_float), ("range", C.c_float), ("innerCone", C.c_float),
+                ("outerCone", C.c_float), ("instance", C.c_uint32), ("primitive", C.c_uint32), ("type", C.c_uint32)]
+
+
+class LaunchParams(C.Structure):
+    """rt_launch_params (include/rt_types.h), 344 bytes."""
+    _fields_ = ([(n, C.c_void_p) for n in (
+        "output", "accumulation", "diffuse", "reflection", "refraction", "caustics", "albedoGuide", "normalGuide",
+        "display", "display2", "display3", "composite", "materials", "textures", "lights", "environment",
+        "environmentCdf", "photons", "photonCount", "sortedPhotons", "photonCellStart")] +
+        [("scene", C.c_uint64)] +
+        [(n, Float3) for n in ("eye", "cameraU", "cameraV", "cameraW", "lensU", "lensV")] +
+        [(n, C.c_float) for n in ("aperture", "focusDistance", "lightWeight", "environmentWeight",
+                                  "environmentRotation", "environmentStrength", "exposure")] +
+        [("sceneCenter", Float3), ("sceneRadius", C.c_float), ("photonRadius", C.c_float)] +
+        [(n, C.c_uint32) for n in ("lightCount", "environmentWidth", "environmentHeight", "width", "height", "sample",
+                                   "maxDepth", "photonBucketCount", "photonCapacity", "photonEmissions", "photonPass")])
+
+
+assert C.sizeof(GpuMaterial) == 272 and C.sizeof(GpuLight) == 92 and C.sizeof(LaunchParams) == 344
+assert C.sizeof(GpuTexture) == 24
+
+_lib = None
+_vp, _u32, _f32 = C.c_void_p, C.c_uint32, C.c_float
+_SIG = {
+    "rth_last_error": (C.c_char_p, []),
+    "rth_scene_create": (_vp, []),
+    "rth_scene_destroy": (None, [_vp]),
+    "rth_scene_add_material": (C.c_int, [_vp, C.POINTER(GpuMaterial)]),
+    "rth_scene_add_geometry": (C.c_int, [_vp, _vp, _u32, _vp, _u32, _u32]),
+    "rth_scene_add_instance": (C.c_int, [_vp, _u32, _vp]),
+    "rth_scene_add_camera": (C.c_int, [_vp, _vp, _f32, _f32, _f32, _f32, _f32]),
+    "rth_scene_add_light": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _f32, _f32, _u32]),
+    "rth_scene_add_image": (C.c_int, [_vp, _vp, _u32, _u32]),
+    "rth_scene_add_texture": (C.c_int, [_vp, C.c_int32, _u32, _u32]),
+    "rth_scene_set_environment": (None, [_vp, _vp, _u32, _u32, _f32, _f32, _f32]),
+    "rth_renderer_create": (_vp, [_vp, _u32, _u32, C.c_int]),
+    "rth_renderer_destroy": (None, [_vp]),
+    "rth_renderer_render": (C.c_int, [_vp, _vp]),
+    "rth_renderer_denoise": (C.c_int, [_vp]),
+    "rth_renderer_set_camera": (C.c_int, [_vp, _vp, _f32, _f32, _f32, _f32, _f32]),
+    "rth_renderer_set_profile": (C.c_int, [_vp, C.c_int]),
+    "rth_renderer_copy_output": (C.c_int, [_vp, _vp]),
+    "rth_renderer_pixels": (C.c_int, [_vp, _vp]),
+    "rth_renderer_linear_pixels": (C.c_int, [_vp, _vp]),
+    "rth_renderer_samples": (_u32, [_vp]),
+    "rth_renderer_set_photon_budget": (C.c_int, [_vp, _u32, _u32, _u32]),
+    "rth_renderer_set_pixel_range": (C.c_int, [_vp, _u32, _u32]),
+    "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
+    "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
+    "rth_renderer_begin_photon_pass": (C.c_int, [_vp]),
+    "rth_renderer_trace_photon_range": (C.c_int, [_vp, _u32, _u32, C.POINTER(_u32)]),
+    "rth_renderer_photon_buffer": (_vp, [_vp]),
+    "rth_renderer_photon_capacity": (_u32, [_vp]),
+    "rth_renderer_photon_emissions": (_u32, [_vp]),
+    "rth_renderer_finish_photon_pass": (C.c_int, [_vp, _u32]),
+    "rth_renderer_accumulation_buffer": (_vp, [_vp, C.c_int]),
+    "rth_renderer_statistics": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rth_renderer_synchronize": (C.c_int, [_vp]),
+    "rth_renderer_launch_params": (None, [_vp, C.POINTER(LaunchParams)]),
+    "rth_renderer_caustic_radius": (_f32, [_vp]),
+}
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    engine.load()
+    if not os.path.exists(HOST_LIB_PATH):
+        raise engine.EngineError(f"{HOST_LIB_PATH} is missing: build it with `make -C raytracer_amd/host`")
+    lib = C.CDLL(HOST_LIB_PATH)
+    for name, (restype, argtypes) in _SIG.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != 0:
+        raise engine.EngineError(load().rth_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gpu_material(m):
+    """dict (workloads.default_material) -> GpuMaterial."""
+    g = GpuMaterial()
+    g.baseColor = Float4(*m["baseColor"])
+    g.emissive = Float3(*m["emissive"])
+    g.attenuationColor = Float3(*m["attenuationColor"])
+    for k in ("metallic", "roughness", "transmission", "ior", "thickness", "attenuationDistance", "emissiveStrength",
+              "dispersion"):
+        setattr(g, k, m[k])
+    for k in ("baseColorTexture", "metallicRoughnessTexture", "normalTexture", "emissiveTexture",
+              "transmissionTexture", "thicknessTexture"):
+        t = m.get(k)
+        ref = GpuTextureRef(-1, 0, Float2(0.0, 0.0), Float2(1.0, 1.0), 0.0, 1.0)
+        if t is not None:
+            ref = GpuTextureRef(t.get("texture", -1), t.get("texCoord", 0), Float2(*t.get("offset", (0.0, 0.0))),
+                                Float2(*t.get("scale", (1.0, 1.0))), t.get("rotation", 0.0), t.get("strength", 1.0))
+        setattr(g, k, ref)
+    return g
+
+
+class HostScene:
+    """rt::Scene built from a workloads scene dict."""
+
+    def __init__(self, scene):
+        lib = load()
+        self.handle = C.c_void_p(lib.rth_scene_create())
+        for m in scene["materials"]:
+            lib.rth_scene_add_material(self.handle, C.byref(gpu_material(m)))
+        for g in scene["geometries"]:
+            v = np.ascontiguousarray(g["vertices"], dtype=np.float32)
+            i = np.ascontiguousarray(g["indices"], dtype=np.uint32)
+            lib.rth_scene_add_geometry(self.handle, _p(v), v.shape[0], _p(i), i.shape[0], g["material"])
+        for gi, m in scene["instances"]:
+            mm = np.ascontiguousarray(m, dtype=np.float32)
+            lib.rth_scene_add_instance(self.handle, gi, _p(mm))
+        for c in scene["cameras"]:
+            mm = np.ascontiguousarray(c["transform"], dtype=np.float32)
+            lib.rth_scene_add_camera(self.handle, _p(mm), c["verticalFov"], c["aspectRatio"], c["nearPlane"],
+                                     c["aperture"], c["focusDistance"])
+        for l in scene["lights"]:
+            mm = np.ascontiguousarray(l["transform"], dtype=np.float32)
+            col = np.ascontiguousarray(l["color"], dtype=np.float32)
+            lib.rth_scene_add_light(self.handle, _p(mm), _p(col), l["intensity"], l["range"], l["innerCone"],
+                                    l["outerCone"], l["type"])
+        for img in scene.get("images", []):
+            px = np.ascontiguousarray(img, dtype=np.uint8)
+            lib.rth_scene_add_image(self.handle, _p(px), px.shape[1], px.shape[0])
+        for t in scene.get("textures", []):
+            lib.rth_scene_add_texture(self.handle, t["image"], t.get("wrapU", 10497), t.get("wrapV", 10497))
+        env = scene.get("environment")
+        if env is not None:
+            px = np.ascontiguousarray(env["pixels"], dtype=np.float32)
+            lib.rth_scene_set_environment(self.handle, _p(px), px.shape[1], px.shape[0], env.get("rotation", 0.0),
+                                          env.get("strength", 1.0), env.get("exposure", 0.0))
+
+    def close(self):
+        if self.handle:
+            load().rth_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """rt::Renderer: Renderer(scene, width, height, profile); render(); pixels(); linear_pixels(); samples()."""
+
+    def __init__(self, scene, width, height, profile=PREVIEW):
+        lib = load()
+        self._scene = scene if isinstance(scene, HostScene) else HostScene(scene)
+        self.width, self.height = width, height
+        handle = lib.rth_renderer_create(self._scene.handle, width, height, profile)
+        if not handle:
+            raise engine.EngineError(lib.rth_last_error().decode())
+        self.handle = C.c_void_p(handle)
+
+    def render(self, output=None):
+        _check(load().rth_renderer_render(self.handle, C.c_void_p(output.data_ptr()) if output is not None else None))
+
+    def denoise(self):
+        _check(load().rth_renderer_denoise(self.handle))
+
+    def set_camera(self, c):
+        mm = np.ascontiguousarray(c["transform"], dtype=np.float32)
+        _check(load().rth_renderer_set_camera(self.handle, _p(mm), c["verticalFov"], c["aspectRatio"], c["nearPlane"],
+                                              c["aperture"], c["focusDistance"]))
+
+    def set_profile(self, profile):
+        _check(load().rth_renderer_set_profile(self.handle, profile))
+
+    def copy_output(self, tensor):
+        _check(load().rth_renderer_copy_output(self.handle, C.c_void_p(tensor.data_ptr())))
+
+    def pixels(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        _check(load().rth_renderer_pixels(self.handle, _p(out)))
+        return out
+
+    def linear_pixels(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        _check(load().rth_renderer_linear_pixels(self.handle, _p(out)))
+        return out
+
+    def samples(self):
+        return int(load().rth_renderer_samples(self.handle))
+
+    # ---- hooks beyond the reference interface ----
+    def set_photon_budget(self, emissions, capacity, buckets):
+        _check(load().rth_renderer_set_photon_budget(self.handle, emissions, capacity, buckets))
+
+    def set_pixel_range(self, begin, end):
+        _check(load().rth_renderer_set_pixel_range(self.handle, begin, end))
+
+    def set_manual_photon_passes(self, manual=True):
+        load().rth_renderer_set_manual_photon_passes(self.handle, int(manual))
+
+    def photon_pass_due(self):
+        return bool(load().rth_renderer_photon_pass_due(self.handle))
+
+    def begin_photon_pass(self):
+        _check(load().rth_renderer_begin_photon_pass(self.handle))
+
+    def trace_photon_range(self, first, count):
+        stored = C.c_uint32(0)
+        _check(load().rth_renderer_trace_photon_range(self.handle, first, count, C.byref(stored)))
+        return stored.value
+
+    def photon_buffer(self):
+        return int(load().rth_renderer_photon_buffer(self.handle) or 0)
+
+    def photon_capacity(self):
+        return int(load().rth_renderer_photon_capacity(self.handle))
+
+    def photon_emissions(self):
+        return int(load().rth_renderer_photon_emissions(self.handle))
+
+    def finish_photon_pass(self, total):
+        _check(load().rth_renderer_finish_photon_pass(self.handle, total))
+
+    def accumulation_buffer(self, index=0):
+        return int(load().rth_renderer_accumulation_buffer(self.handle, index) or 0)
+
+    def statistics(self):
+        out = (C.c_uint64 * 4)()
+        _check(load().rth_renderer_statistics(self.handle, out))
+        return dict(extend_rays=out[0], shadow_rays=out[1], gather_queries=out[2], gathered_photons=out[3])
+
+    def synchronize(self):
+        _check(load().rth_renderer_synchronize(self.handle))
+
+    def launch_params(self):
+        p = LaunchParams()
+        load().rth_renderer_launch_params(self.handle, C.byref(p))
+        return p
+
+    def caustic_radius(self):
+        return float(load().rth_renderer_caustic_radius(self.handle))
+
+    def close(self):
+        if self.handle:
+            load().rth_renderer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_to_host(ptr, nbytes):
+    """Copies nbytes from a raw device address into a numpy byte array (hipMemcpy through torch's runtime)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    out = np.empty(nbytes, dtype=np.uint8)
+    torch.cuda.synchronize()
+    status = hip.hipMemcpy(_p(out), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))  # hipMemcpyDeviceToHost
+    if status != 0:
+        raise engine.EngineError(f"hipMemcpy failed with {status}")
+    return out

@@ -392,3 +392,86 @@ def camera_rays(scene, width, height, seed=0, camera=0):
     org = np.concatenate([np.tile(eye, (n, 1)), np.full((n, 1), 0.001)], axis=1).astype(np.float32)
     dr = np.concatenate([d.reshape(-1, 3), np.full((n, 1), 1e16)], axis=1).astype(np.float32)
     return np.ascontiguousarray(org), np.ascontiguousarray(dr)
+
+
+def torus_mesh(major=0.25, minor=0.03, segments_u=96, segments_v=24):
+    u = np.arange(segments_u) / segments_u * 2.0 * math.pi
+    v = np.arange(segments_v) / segments_v * 2.0 * math.pi
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    ring = major + minor * np.cos(vv)
+    pos = np.stack([ring * np.cos(uu), minor * np.sin(vv), ring * np.sin(uu)], axis=-1).reshape(-1, 3)
+    nrm = np.stack([np.cos(vv) * np.cos(uu), np.sin(vv), np.cos(vv) * np.sin(uu)], axis=-1).reshape(-1, 3)
+    iu, iv = np.arange(segments_u), np.arange(segments_v)
+    a = (iu[:, None] * segments_v + iv[None, :]).reshape(-1)
+    b = (((iu + 1) % segments_u)[:, None] * segments_v + iv[None, :]).reshape(-1)
+    c = (((iu + 1) % segments_u)[:, None] * segments_v + ((iv + 1) % segments_v)[None, :]).reshape(-1)
+    d = (iu[:, None] * segments_v + ((iv + 1) % segments_v)[None, :]).reshape(-1)
+    idx = np.concatenate([np.stack([a, c, b], axis=1), np.stack([a, d, c], axis=1)]).astype(np.uint32)
+    uv = np.stack([uu.reshape(-1) / (2 * math.pi), vv.reshape(-1) / (2 * math.pi)], axis=1)
+    return make_vertices(pos.astype(np.float32), nrm.astype(np.float32), uv.astype(np.float32)), idx
+
+
+def checker_image(size=64, a=(200, 60, 60, 255), b=(240, 240, 240, 255), squares=8):
+    y, x = np.mgrid[0:size, 0:size]
+    mask = ((x * squares // size) + (y * squares // size)) % 2 == 0
+    img = np.where(mask[:, :, None], np.array(a, np.uint8), np.array(b, np.uint8)).astype(np.uint8)
+    return np.ascontiguousarray(img)
+
+
+def sky_environment(width=64, height=32, sun=(0.3, 0.6)):
+    """Small latitude/longitude sky: blue-to-white gradient with a bright sun disc."""
+    v, u = np.mgrid[0:height, 0:width]
+    theta = (v + 0.5) / height * math.pi
+    up = np.cos(theta)
+    sky = np.stack([0.35 + 0.25 * (1 - up), 0.5 + 0.2 * (1 - up), 0.9 * np.ones_like(up), np.ones_like(up)], -1)
+    su, sv = sun[0] * width, (1 - sun[1]) * 0.5 * height
+    d2 = (u - su) ** 2 + (v - sv) ** 2
+    sky[..., :3] += (40.0 * np.exp(-d2 / 1.5))[..., None]
+    return np.ascontiguousarray(sky.astype(np.float32))
+
+
+def caustic_lab(glass_subdivisions=3):
+    """Diffuse table, a gold ring (metallic mirror branch), a faceted glass ball
+    (transmission) and one spot light from above: caustics on the table."""
+    table = quad([-1, 0, -1], [-1, 0, 1], [1, 0, 1], [1, 0, -1])
+    ring = torus_mesh()
+    ball = icosphere(glass_subdivisions)
+    materials = [default_material(metallic=1.0),
+                 default_material(baseColor=(0.8, 0.8, 0.8, 1.0)),
+                 default_material(baseColor=(1.0, 0.78, 0.34, 1.0), metallic=1.0, roughness=0.05),
+                 default_material(baseColor=(1.0, 1.0, 1.0, 1.0), transmission=1.0, roughness=0.0, ior=1.5,
+                                  dispersion=0.02)]
+    geos = [{"vertices": table[0], "indices": table[1], "material": 1},
+            {"vertices": ring[0], "indices": ring[1], "material": 2},
+            {"vertices": ball[0], "indices": ball[1], "material": 3}]
+    inst = [(0, np.eye(4, dtype=np.float32).reshape(-1)),
+            (1, translation(-0.3, 0.031, 0.0)),
+            (2, translation(0.3, 0.15, 0.05, 0.15))]
+    lights = [dict(transform=look_at([0.6, 1.5, 0.4], [0.0, 0.0, 0.0]), color=(1.0, 0.97, 0.9), intensity=60.0,
+                   range=float("inf"), innerCone=0.25, outerCone=0.45, type=1)]
+    camera = dict(transform=look_at([0.0, 0.9, 1.3], [0.0, 0.05, 0.0]), verticalFov=0.6, aspectRatio=0.0,
+                  nearPlane=0.01, aperture=0.0, focusDistance=1.5)
+    return dict(geometries=geos, instances=inst, materials=materials, lights=lights, cameras=[camera],
+                environment=None)
+
+
+def textured_sky_scene():
+    """Checker-textured floor, a rough metal and a glass ball under a sky environment
+    with a sun, seen through a thin lens: textures, environment sampling, MIS."""
+    floor = quad([-2, 0, -2], [-2, 0, 2], [2, 0, 2], [2, 0, -2])
+    ball = icosphere(3)
+    materials = [default_material(metallic=1.0),
+                 default_material(baseColorTexture=dict(texture=0, scale=(4.0, 4.0), rotation=0.3)),
+                 default_material(baseColor=(0.9, 0.9, 0.95, 1.0), metallic=1.0, roughness=0.35),
+                 default_material(transmission=0.9, roughness=0.1, ior=1.45, attenuationColor=(0.4, 0.9, 0.5),
+                                  attenuationDistance=0.5)]
+    geos = [{"vertices": floor[0], "indices": floor[1], "material": 1},
+            {"vertices": ball[0], "indices": ball[1], "material": 2},
+            {"vertices": ball[0], "indices": ball[1], "material": 3}]
+    inst = [(0, np.eye(4, dtype=np.float32).reshape(-1)), (1, translation(-0.6, 0.5, 0.0, 0.5)),
+            (2, rotation_y(0.5, 0.6, 0.4, 0.2, 0.4))]
+    camera = dict(transform=look_at([0.0, 1.2, 3.0], [0.0, 0.4, 0.0]), verticalFov=0.6, aspectRatio=0.0,
+                  nearPlane=0.01, aperture=0.02, focusDistance=3.0)
+    return dict(geometries=geos, instances=inst, materials=materials, lights=[], cameras=[camera],
+                images=[checker_image()], textures=[dict(image=0)],
+                environment=dict(pixels=sky_environment(), rotation=0.4, strength=1.2, exposure=-0.5))

@@ -1,0 +1,187 @@
+"""GPU tests of the wavefront integrator and the photon tracer behind rt::Renderer,
+against the oracle's scalar restatement of the reference's device programs.
+
+Tolerance: libm (host) and the device math library round sinf/cosf/powf/... differently in the last
+place, so a path can take a different branch than its oracle twin; those are rare, the rest agree to
+float rounding.  Stated per test: the share of pixels within 1e-3 relative error, and the relative
+RMSE of the whole image at equal sample count."""
+import numpy as np
+import pytest
+
+from raytracer_amd import workloads
+from helpers import HostParams, oracle_scene, rel_rmse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R(engine):
+    from raytracer_amd import renderer
+    renderer.load()
+    return renderer
+
+
+def render_both(R, oracle, scene, width, height, samples, profile=0, threads=8):
+    r = R.Renderer(scene, width, height, profile)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    for s in range(samples):
+        r.render()
+        host.params.sample = s
+        ref.render_sample(host.params, 0, width * height, threads)
+    r.synchronize()
+    gpu = r.linear_pixels().reshape(-1, 4)
+    return r, host, gpu, host.aov[0]
+
+
+def close_fraction(a, b, rel=1e-3, floor=1e-4):
+    err = np.abs(a[:, :3].astype(np.float64) - b[:, :3])
+    tol = rel * np.maximum(np.abs(b[:, :3]), floor)
+    return float((err <= tol).all(axis=1).mean())
+
+
+def test_cornell_point_light_matches_oracle(R, oracle):
+    scene = workloads.cornell_box()
+    r, host, gpu, cpu = render_both(R, oracle, scene, 256, 256, 1)
+    assert r.samples() == 1
+    assert (gpu[:, 3] == 1.0).all()
+    assert cpu[:, :3].mean() > 0.01
+    assert close_fraction(gpu, cpu) > 0.995
+    assert rel_rmse(gpu[:, :3], cpu[:, :3]) < 2e-2
+    # the byte image follows the same tone curve
+    diff = np.abs(r.pixels().reshape(-1, 4).astype(int) - host.output.astype(int))
+    assert (diff <= 1).mean() > 0.995
+    stats = r.statistics()
+    assert stats["extend_rays"] >= 256 * 256 and stats["shadow_rays"] > 0 and stats["gather_queries"] == 0
+
+
+def test_cornell_golden_image(R):
+    """The committed oracle image of config 1 (Cornell, 1 spp, depth 5; 128 x 128 to keep the fixture small)."""
+    import os
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_128_1spp.npz"))["accumulation"]
+    r = R.Renderer(workloads.cornell_box(), 128, 128, 0)
+    r.render()
+    gpu = r.linear_pixels().reshape(-1, 4)
+    assert close_fraction(gpu, golden.reshape(-1, 4)) > 0.995
+
+
+def test_area_light_mis_several_samples(R, oracle):
+    scene = workloads.cornell_box(light="panel")
+    r, host, gpu, cpu = render_both(R, oracle, scene, 96, 96, 4)
+    assert close_fraction(gpu, cpu) > 0.98
+    assert rel_rmse(gpu[:, :3], cpu[:, :3]) < 5e-2
+    for k in range(1, 7):  # every accumulation buffer, not only the beauty image
+        from raytracer_amd import renderer as Rm
+        dev = Rm.device_to_host(r.accumulation_buffer(k), 96 * 96 * 16).view(np.float32).reshape(-1, 4)
+        assert close_fraction(dev, host.aov[k]) > 0.97, k
+
+
+def test_textures_environment_lens_glass_metal(R, oracle):
+    scene = workloads.textured_sky_scene()
+    r, host, gpu, cpu = render_both(R, oracle, scene, 128, 72, 2)
+    assert cpu[:, :3].mean() > 0.05
+    assert close_fraction(gpu, cpu, rel=2e-3) > 0.95
+    # bright sun samples make single pixels heavy; compare the robust bulk
+    keep = cpu[:, :3].max(axis=1) < np.percentile(cpu[:, :3].max(axis=1), 99)
+    assert rel_rmse(gpu[keep, :3], cpu[keep, :3]) < 0.1
+
+
+def test_photon_pass_matches_oracle(R, oracle):
+    scene = workloads.caustic_lab()
+    r = R.Renderer(scene, 64, 36, 1)
+    r.set_photon_budget(1 << 17, 1 << 16, 1 << 14)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    r.begin_photon_pass()
+    stored = r.trace_photon_range(0, 1 << 17)
+    gpu = R.device_to_host(r.photon_buffer(), stored * 36).view(np.float32).reshape(-1, 9)
+    host.params.photonRadius = r.caustic_radius()
+    cpu, wanted = ref.trace_photons(host.params, 0, 1 << 17, 1 << 16, threads=8)
+    assert wanted > 1000
+    assert abs(stored - wanted) <= max(4, wanted // 500)
+    # emission order: align the two lists through their common prefix of exactly equal photons
+    n = min(len(gpu), len(cpu))
+    same = np.isclose(gpu[:n], cpu[:n], rtol=1e-3, atol=1e-5).all(axis=1)
+    assert same[: n // 4].mean() > 0.9
+    # sharded emission ranges append in emission order: two halves equal one pass
+    r.begin_photon_pass()
+    a = r.trace_photon_range(0, 1 << 16)
+    b = r.trace_photon_range(1 << 16, 1 << 16)
+    assert b == stored and a <= b
+    again = R.device_to_host(r.photon_buffer(), stored * 36).view(np.float32).reshape(-1, 9)
+    assert np.array_equal(again, gpu)
+
+
+def test_final_profile_caustics(R, oracle):
+    scene = workloads.caustic_lab()
+    w, h = 96, 54
+    r = R.Renderer(scene, w, h, 1)
+    r.set_photon_budget(1 << 18, 1 << 17, 1 << 15)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    radius = r.caustic_radius()
+    for s in range(2):
+        r.render()
+        if s % 4 == 0:  # renderer.cpp:780: a photon pass before samples 0, 4, 8, ...
+            host.params.photonRadius = radius
+            host.params.photonPass = s // 4
+            ph, wanted = ref.trace_photons(host.params, 0, 1 << 18, 1 << 17, threads=8)
+            offsets, srt = oracle.build_photon_grid(ph, radius, 1 << 15)
+            host.sorted[: len(srt)] = srt
+            host.cell_start[:] = offsets
+        host.params.sample = s
+        ref.render_sample(host.params, 0, w * h, 8)
+    r.synchronize()
+    gpu = r.linear_pixels().reshape(-1, 4)
+    from raytracer_amd import renderer as Rm
+    caustic_gpu = Rm.device_to_host(r.accumulation_buffer(4), w * h * 16).view(np.float32).reshape(-1, 4)
+    caustic_cpu = host.aov[4]
+    assert caustic_cpu[:, :3].sum() > 0 and caustic_gpu[:, :3].sum() > 0
+    # photon sets differ in a few members (transcendental rounding), so the density estimate is
+    # compared in aggregate: total caustic energy within 3 %, image relRMSE bounded
+    assert abs(caustic_gpu[:, :3].sum() / caustic_cpu[:, :3].sum() - 1.0) < 0.03
+    assert rel_rmse(gpu[:, :3], host.aov[0][:, :3]) < 0.15
+    stats = r.statistics()
+    assert stats["gather_queries"] > 0
+
+
+def test_reference_error_behaviour(R):
+    scene = workloads.cornell_box()
+    empty = dict(scene, instances=[])
+    with pytest.raises(Exception, match="no geometry"):
+        R.Renderer(empty, 8, 8)
+    nocam = dict(scene, cameras=[])
+    with pytest.raises(Exception, match="no perspective camera"):
+        R.Renderer(nocam, 8, 8)
+    r = R.Renderer(scene, 8, 8)
+    with pytest.raises(Exception, match="denois"):
+        r.denoise()
+
+
+def test_set_camera_and_profile_reset_accumulation(R):
+    scene = workloads.cornell_box()
+    r = R.Renderer(scene, 32, 32)
+    r.render()
+    r.render()
+    assert r.samples() == 2
+    r.set_camera(scene["cameras"][0])
+    assert r.samples() == 0 and not r.linear_pixels().any()
+    r.render()
+    r.set_profile(1)
+    assert r.samples() == 0 and not r.linear_pixels().any()
+
+
+def test_pixel_ranges_compose_to_the_full_frame(R):
+    """Tile sharding: rendering two pixel ranges gives the same buffers as one full-frame launch."""
+    scene = workloads.cornell_box(light="panel")
+    w, h = 64, 64
+    full = R.Renderer(scene, w, h)
+    full.render()
+    full.render()
+    parts = R.Renderer(scene, w, h)
+    for s in range(2):
+        # both halves of sample s: the sample counter advances per render(), so drive it per range
+        parts.set_pixel_range(0, w * h // 3)
+        parts.render()
+    a = parts.linear_pixels().reshape(-1, 4)[: w * h // 3]
+    assert np.array_equal(a, full.linear_pixels().reshape(-1, 4)[: w * h // 3])
