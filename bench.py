@@ -1,23 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the ray-intersection + photon-gather path on MI355X.
 
-One "step" is one pass of the hot path over one resident batch of synthetic
-input: the closest-hit kernel over every ray of a 1-sample-per-pixel, 5-bounce
-frame of the Dragon-Cornell stand-in at 1920x1080 (primary rays plus four
-generations of bounce rays), followed by one photon-grid build and one
-radius-gather pass over the reference-size photon map.  The headline value is
-closest-hit rays per second over the whole job; photon gathers/s and the grid
-build time ride along in the same JSON line.
+One "step" is one pass of the hot path over one frame of synthetic input: one camera sample per
+pixel of the Dragon-Cornell stand-in (a ~870k-triangle absorbing-glass mesh in a Cornell box with an
+emissive panel) at 1920x1080, preview profile (5 bounces), through rt::Renderer::render(): generate,
+then per bounce extend (closest hit) / shade / shadow, then accumulate.  Scene, BVH and every buffer
+are resident in HBM before the timed region.  The headline value is rays traced (extend + shadow)
+per second over the whole step; the extend kernel's share is priced against the HBM roofline.
+
+After the timed steps the photon map of the reference's size (2^23 photons, 2^22 buckets) is built
+and gathered once per step count for the second metric (photon gathers/s, grid build time).
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch with torch.distributed.run (one rank per GPU); every rank
-holds a replica of the BVH and traces the frame for its own sample index (weak
-scaling, no collective on the data path).
+For N > 1 launch with torch.distributed.run, one rank per GPU: every rank holds a replica of the
+scene and renders the frame for its own sample indices (rank, rank + N, ...) - weak scaling, no
+collective on the data path.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -28,51 +29,115 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+NODE_BYTES, TRIANGLE_BYTES, RAY_IO_BYTES = 80.0, 36.0, 52.0  # algorithmic bytes: wide node, 3 x float3, ray in + hit out
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--bounces", type=int, default=5)
-    p.add_argument("--workload", default="dragon-cornell", choices=["dragon-cornell", "soup1m", "sphere-field"])
+    p.add_argument("--workload", default="dragon-cornell",
+                   choices=["dragon-cornell", "cornell", "sphere-field", "caustic-lab"])
     p.add_argument("--photons", type=int, default=1 << 23)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-photon-bench", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
 
-def build_scene(eng, scene):
+def make_scene(name):
+    from raytracer_amd import workloads
+    if name == "dragon-cornell":
+        return workloads.dragon_cornell(), 0
+    if name == "cornell":
+        return workloads.cornell_box(light="panel"), 0
+    if name == "sphere-field":
+        return workloads.sphere_field(), 0
+    return workloads.caustic_lab(), 1
+
+
+def photon_benchmark(eng, workloads, args, rank, steps):
+    """Grid build + gather over the reference-size photon map; queries are one per pixel of a frame
+    looking at the table (row-major, so neighbouring lanes query neighbouring cells)."""
     import torch
-    blases = []
+    n_ph, buckets = args.photons, workloads.PHOTON_BUCKETS
+    photons = torch.from_numpy(workloads.caustic_photons(n_ph, seed=2 + rank)).cuda()
+    radius = 0.0015
+    grid = eng.PhotonGrid(n_ph, buckets)
+    w, h = args.width, args.height
+    xs = (np.arange(w, dtype=np.float32) + 0.5) / w * 2.0 - 1.0
+    zs = ((np.arange(h, dtype=np.float32) + 0.5) / h * 2.0 - 1.0) * (h / w)
+    qp = np.zeros((h, w, 3), dtype=np.float32)
+    qp[..., 0], qp[..., 2] = xs[None, :], zs[:, None]
+    qn = np.zeros_like(qp)
+    qn[..., 1] = 1.0
+    qp, qn = torch.from_numpy(qp.reshape(-1, 3)).cuda(), torch.from_numpy(qn.reshape(-1, 3)).cuda()
+    flux = torch.empty_like(qp)
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+    grid.build(photons, radius, stream=stream)
+    grid.gather(qp, qn, stream=stream, out=flux, visited=visited)
+    per_query = float(visited.item()) / qp.shape[0]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    for k in range(steps):
+        ev[k][0].record(stream)
+        grid.build(photons, radius, stream=stream)
+        ev[k][1].record(stream)
+        grid.gather(qp, qn, stream=stream, out=flux)
+        ev[k][2].record(stream)
+    torch.cuda.synchronize()
+    build_ms = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
+    gather_ms = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
+    gather_bytes = 36.0 + 27.0 * 8.0 + 36.0 * per_query  # query in + flux out, 27 cell ranges, photons read
+    return {
+        "photons": n_ph, "buckets": buckets, "queries": int(qp.shape[0]), "radius": radius,
+        "photons_read_per_query": per_query,
+        "gathers_per_s": qp.shape[0] / (gather_ms * 1e-3),
+        "gather_ms": gather_ms,
+        "gather_gbs": qp.shape[0] * gather_bytes / (gather_ms * 1e-3) / 1e9,
+        "gather_frac_of_hbm_peak": qp.shape[0] * gather_bytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "grid_build_ms": build_ms,
+        "grid_build_gbs": (84.0 * n_ph + 4.0 * (buckets + 1)) / (build_ms * 1e-3) / 1e9,
+        "grid_build_frac_of_hbm_peak": (84.0 * n_ph + 4.0 * (buckets + 1)) / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+
+
+def cpu_baseline(scene, args, width, height, profile):
+    """The oracle's integrator (same frame, sample 0) on the host cores over a bounded band of pixel
+    rows from the middle of the image, rays counted the way the GPU counts them."""
+    from oracle import binding as orc  # the CPU baseline leg: the oracle, timed, never shipped
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ref_setup import Setup
+    ref = orc.Scene()
     for g in scene["geometries"]:
-        v = torch.from_numpy(np.ascontiguousarray(g["vertices"], dtype=np.float32)).cuda()
-        i = torch.from_numpy(np.ascontiguousarray(g["indices"].astype(np.int32))).cuda()
-        blases.append(eng.Blas(v, i))
-    return eng.Scene([(blases[gi], m) for gi, m in scene["instances"]]), blases
-
-
-def bounce_rays(org, dirs, hits, seed):
-    """Next ray generation: from every hit point into a random direction of the
-    hemisphere around the reversed incoming ray (synthetic stand-in for a
-    diffuse bounce).  Torch ops on the device; only used to prepare inputs."""
-    import torch
-    found = hits[:, 3].view(torch.int32) != -1
-    t = hits[found, 0:1]
-    p = org[found, :3] + dirs[found, :3] * t
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(seed)
-    d = torch.randn((p.shape[0], 3), device="cuda", generator=gen)
-    d = d / d.norm(dim=1, keepdim=True)
-    flip = (d * dirs[found, :3]).sum(1, keepdim=True) > 0
-    d = torch.where(flip, -d, d)
-    o = p - dirs[found, :3] * 1e-3
-    org2 = torch.cat([o, torch.full((p.shape[0], 1), 0.001, device="cuda")], 1).contiguous()
-    dir2 = torch.cat([d, torch.full((p.shape[0], 1), 1e16, device="cuda")], 1).contiguous()
-    return org2, dir2
+        ref.add_geometry(g["vertices"], g["indices"], g["material"])
+    for gi, m in scene["instances"]:
+        ref.add_instance(gi, m)
+    ref.commit()
+    threads = min(16, os.cpu_count() or 1)
+    setup = Setup(scene, width, height, final=False)  # preview path lengths; no photon map on the CPU leg
+    setup.params.sample = 0
+    mid = height // 2
+    orc.ray_counter(reset=True)
+    t1 = time.perf_counter()
+    ref.render_sample(setup.params, mid * width, (mid + 2) * width, threads)
+    probe_s = time.perf_counter() - t1
+    probe_rays = orc.ray_counter(reset=True)
+    rows = int(max(2, min(height // 2, 2 * args.cpu_seconds / max(probe_s, 1e-6))))
+    first = (height - rows) // 2
+    t1 = time.perf_counter()
+    ref.render_sample(setup.params, first * width, (first + rows) * width, threads)
+    cpu_s = time.perf_counter() - t1
+    rays = orc.ray_counter(reset=True)
+    return {
+        "value": rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{rows} pixel rows ({rows * width} paths, {rays} rays) from the middle of the same frame, "
+                  f"sample 0, preview depth, the oracle's integrator over its own BVH, {threads} std::thread workers "
+                  f"(probe: {probe_rays} rays in {probe_s:.2f} s)",
+    }
 
 
 def main():
@@ -80,6 +145,7 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracer_amd import engine as eng
+    from raytracer_amd import renderer as R
     from raytracer_amd import workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,134 +156,97 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    eng.load()
+    R.load()
 
-    # ---- scene + rays (resident in HBM before the timed region) ----
-    if args.workload == "dragon-cornell":
-        scene = workloads.dragon_cornell()
-    elif args.workload == "soup1m":
-        scene = workloads.triangle_soup(1_000_000)
-    else:
-        scene = workloads.sphere_field()
-    top, blases = build_scene(eng, scene)
-    stats = top.stats()
-    if scene["cameras"]:
-        o, d = workloads.camera_rays(scene, args.width, args.height, seed=rank)
-    else:
-        o, d = workloads.random_rays(scene, args.width * args.height, seed=rank)
-    org, dirs = [torch.from_numpy(o).cuda()], [torch.from_numpy(d).cuda()]
-    for b in range(1, args.bounces):
-        hits, _ = top.trace_closest(org[-1], dirs[-1])
-        o2, d2 = bounce_rays(org[-1], dirs[-1], hits, seed=1000 * rank + b)
-        if o2.shape[0] == 0:
-            break
-        org.append(o2)
-        dirs.append(d2)
-    org_all = torch.cat(org).contiguous()
-    dir_all = torch.cat(dirs).contiguous()
-    n_rays = org_all.shape[0]
-    hits = torch.empty((n_rays, 4), dtype=torch.float32, device="cuda")
-    inst = torch.empty(n_rays, dtype=torch.int32, device="cuda")
+    scene, profile = make_scene(args.workload)
+    renderer = R.Renderer(scene, args.width, args.height, profile)
+    renderer.set_sample_sequence(rank, world)
+    if profile == R.FINAL:
+        renderer.set_photon_budget(1 << 24, 1 << 23, 1 << 22)
 
-    # per-ray traversal averages (for the algorithmic byte count), outside the timed region
-    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
-    top.trace_closest(org_all, dir_all, counters=counters, hits=hits, inst=inst)
-    c = counters.cpu().numpy().astype(np.float64)
-    nodes_per_ray, tris_per_ray = c[1] / c[0], c[2] / c[0]
-    bytes_per_ray = 52.0 + nodes_per_ray * 80.0 + tris_per_ray * 36.0
+    # traversal averages per ray (for the algorithmic byte count), outside the timed region
+    renderer.set_measurement(count_traversal=True)
+    renderer.render()
+    c = renderer.statistics()
+    nodes_per_ray = c["nodes"] / max(c["extend_rays"], 1)
+    tris_per_ray = c["triangles"] / max(c["extend_rays"], 1)
+    bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
-    # ---- photon map (reference sizes) ----
-    n_ph = args.photons
-    buckets = workloads.PHOTON_BUCKETS
-    photons = torch.from_numpy(workloads.caustic_photons(n_ph, seed=2 + rank)).cuda()
-    radius = 0.0015
-    grid = eng.PhotonGrid(n_ph, buckets)
-    qp, qn = workloads.gather_queries(args.width * args.height, seed=7 + rank)
-    qp, qn = torch.from_numpy(qp).cuda(), torch.from_numpy(qn).cuda()
-    flux = torch.empty_like(qp)
-    n_queries = qp.shape[0]
-
-    stream = torch.cuda.current_stream()
-
-    def step(events=None):
-        if events is not None:
-            events[0].record(stream)
-        top.trace_closest(org_all, dir_all, stream=stream, hits=hits, inst=inst)
-        if events is not None:
-            events[1].record(stream)
-        grid.build(photons, radius, stream=stream)
-        if events is not None:
-            events[2].record(stream)
-        grid.gather(qp, qn, stream=stream, out=flux)
-        if events is not None:
-            events[3].record(stream)
-
+    renderer.set_measurement(time_stages=False)
     for _ in range(args.warmup):
-        step()
+        renderer.render()
+    renderer.synchronize()
+    renderer.statistics()
+    renderer.set_measurement(time_stages=True)
+    renderer.stage_timings()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
+    for _ in range(args.steps):
+        renderer.render()
+    renderer.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    stats = renderer.statistics()
+    stages = renderer.stage_timings()
+    rays = float(stats["extend_rays"] + stats["shadow_rays"])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        counts = torch.tensor([n_rays, n_queries], dtype=torch.float64, device="cuda")
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        total_rays, total_queries = float(counts[0].item()), float(counts[1].item())
+        total = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        total_rays, total_gathers = float(total[0].item()), float(total[1].item())
     else:
-        total_rays, total_queries = float(n_rays), float(n_queries)
+        total_rays, total_gathers = rays, float(stats["gather_queries"])
 
-    trace_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    build_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    photon = None
+    if not args.no_photon_bench:
+        photon = photon_benchmark(eng, workloads, args, rank, max(3, min(args.steps, 10)))
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    mrays = total_rays * args.steps / elapsed / 1e6
-    achieved = n_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
+    extend_ms, extend_launches = stages["extend"]
+    achieved = stats["extend_rays"] * bytes_per_ray / (extend_ms * 1e-3) / 1e9
+    p = renderer.launch_params()
     out = {
         "metric": "closest_hit_mrays_per_s",
-        "value": mrays,
+        "value": total_rays / elapsed / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload} stand-in, {args.width}x{args.height}, 1 spp, {args.bounces} ray generations "
-                        f"(primary + synthetic bounces), then photon grid build + gather "
-                        f"({n_ph} photons, {buckets} buckets, {n_queries} queries)",
-            "rays_per_step_per_gpu": n_rays,
-            "triangles": int(stats.triangleCount),
-            "bvh_nodes": int(stats.nodeCount),
-            "bvh_bytes": int(stats.nodeBytes + stats.triangleBytes),
-            "instances": int(stats.instanceCount),
-            "parallelism": f"replicated BVH, {world} x sample-index shards",
+            "workload": f"{args.workload} stand-in, {args.width}x{args.height}, 1 sample per pixel per step, "
+                        f"{'final (32 bounces, photon map)' if profile else 'preview (5 bounces)'}, wavefront "
+                        f"generate/extend/shade/shadow/accumulate through rt::Renderer::render()",
+            "rays_per_step_per_gpu": rays / args.steps,
+            "extend_rays_per_step": stats["extend_rays"] / args.steps,
+            "shadow_rays_per_step": stats["shadow_rays"] / args.steps,
+            "triangles": int(sum(scene["geometries"][g]["indices"].shape[0] for g, _ in scene["instances"])),
+            "instances": len(scene["instances"]),
+            "light_count": int(p.lightCount),
+            "parallelism": f"replicated scene, {world} x sample-index shards, no data-path collective",
         },
-        "trace_kernel_mrays_per_s": n_rays / (trace_ms * 1e-3) / 1e6,
-        "photon_gathers_per_s": total_queries / (gather_ms * 1e-3),
-        "photon_grid_build_ms": build_ms,
-        "photon_grid_build_gbs": (84.0 * n_ph + 4.0 * (buckets + 1)) / (build_ms * 1e-3) / 1e9,
+        "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+        "extend_kernel_mrays_per_s": stats["extend_rays"] / (extend_ms * 1e-3) / 1e6,
+        "shadow_kernel_mrays_per_s": stats["shadow_rays"] / max(stages["shadow"][0] * 1e-3, 1e-9) / 1e6,
+        "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {
             "bound": "hbm",
-            "kernel": "traceKernel<closest>",
+            "kernel": "extendKernel (closest hit)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -226,42 +255,15 @@ def main():
             "bytes_per_ray": bytes_per_ray,
             "nodes_per_ray": nodes_per_ray,
             "triangles_per_ray": tris_per_ray,
-            "kernel_ms": trace_ms,
+            "avg_launch_ms": extend_ms / max(extend_launches, 1),
+            "launches": extend_launches,
         },
     }
-
+    if photon is not None:
+        out["photon_gathers_per_s"] = photon["gathers_per_s"]
+        out["photon"] = photon
     if not args.no_cpu_baseline:
-        from oracle import binding as orc  # the CPU baseline leg: the oracle, timed, never shipped
-        ref = orc.Scene()
-        for g in scene["geometries"]:
-            ref.add_geometry(g["vertices"], g["indices"], g["material"])
-        for gi, m in scene["instances"]:
-            ref.add_instance(gi, m)
-        ref.commit()
-        threads = min(16, os.cpu_count() or 1)
-        rng = np.random.default_rng(0)
-        o_h, d_h = org_all.cpu().numpy(), dir_all.cpu().numpy()
-        probe = rng.choice(n_rays, size=min(n_rays, 100000), replace=False)
-        t1 = time.perf_counter()
-        ref.trace_closest(o_h[probe], d_h[probe], use_bvh=True, threads=threads)
-        rate = len(probe) / (time.perf_counter() - t1)
-        sample = rng.choice(n_rays, size=int(min(n_rays, max(len(probe), rate * args.cpu_seconds))), replace=False)
-        t1 = time.perf_counter()
-        tuv, prim, rinst = ref.trace_closest(o_h[sample], d_h[sample], use_bvh=True, threads=threads)
-        cpu_s = time.perf_counter() - t1
-        # the sample doubles as a parity check of the timed GPU output
-        h = hits.cpu().numpy()
-        same = bool(np.array_equal(h[sample, 3].view(np.uint32), prim) and
-                    np.array_equal(h[sample, 0].view(np.uint32), tuv[:, 0].view(np.uint32)))
-        out["cpu_baseline"] = {
-            "value": len(sample) / cpu_s / 1e6,
-            "unit": "Mrays/s",
-            "cores": threads,
-            "kind": "port",
-            "sample": f"{len(sample)} rays drawn uniformly from the step's {n_rays} rays, oracle BVH, "
-                      f"{threads} std::thread workers",
-            "gpu_output_matches_on_sample": same,
-        }
+        out["cpu_baseline"] = cpu_baseline(scene, args, args.width, args.height, profile)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -185,6 +185,13 @@ void rt_wavefront_destroy(rt_wavefront* wavefront);
 rt_status rt_render_sample(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t pixelBegin,
                            uint32_t pixelEnd, void* stream);
 
+/* Same, with the sample index that seeds the random streams (src/device.cu:882)
+ * given apart from params->sample, which then only sets the running-mean weight
+ * 1 / (sample + 1): lets several GPUs each average their own share of the
+ * sample indices of one image. */
+rt_status rt_render_sample_seeded(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t pixelBegin,
+                                  uint32_t pixelEnd, uint32_t seedSample, void* stream);
+
 /* The photon pass for emission indices [firstEmission, firstEmission +
  * emissionCount) of pass params->photonPass: photons are appended to
  * params->photons behind *params->photonCount in emission order (the reference
@@ -196,10 +203,20 @@ rt_status rt_render_sample(rt_wavefront* wavefront, const rt_launch_params* para
 rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
                            uint32_t emissionCount, void* stream);
 
-/* Copies the running counters to out4 (host): [0] rays through the extend
- * stage, [1] shadow rays, [2] caustic gather queries, [3] photons read by them.
+/* Copies the running counters to out8 (host): [0] rays through the extend
+ * stage, [1] shadow rays, [2] caustic gather queries, [3] photons read by them,
+ * [4] wide nodes visited, [5] triangles tested, [6] instances entered by extend
+ * launches made while RT_WAVEFRONT_COUNT_TRAVERSAL was set, [7] unused.
  * Synchronises `stream`; reset != 0 zeroes the counters afterwards. */
-rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out4, int reset, void* stream);
+rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out8, int reset, void* stream);
+
+/* Measurement switches (both off by default). */
+#define RT_WAVEFRONT_TIME_STAGES 1u      /* bracket every stage launch of rt_render_sample with HIP events */
+#define RT_WAVEFRONT_COUNT_TRAVERSAL 2u  /* extend launches count visited nodes / tested triangles */
+rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
+/* Sums the event-timed launches since the last call per stage: [0] generate,
+ * [1] extend, [2] shade, [3] shadow, [4] accumulate.  Synchronises `stream`. */
+rt_status rt_wavefront_timings(rt_wavefront* wavefront, float* milliseconds5, uint32_t* launches5, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,7 @@ def load():
         "orc_shade_hits": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
         "orc_render_sample": (None, [_vp, _vp, _u32, _u32, C.c_int]),
         "orc_trace_photons": (_u32, [_vp, _vp, _u32, _u32, _vp, _u32, C.c_int]),
+        "orc_ray_counter": (C.c_uint64, [C.c_int]),
     }
     for name, (restype, argtypes) in sig.items():
         fn = getattr(lib, name)
@@ -107,6 +108,10 @@ def random_stream(state, count):
     lib = load()
     vals = np.array([lib.orc_random(C.byref(s)) for _ in range(count)], dtype=np.float32)
     return vals, s.value
+
+
+def ray_counter(reset=False):
+    return int(load().orc_ray_counter(int(reset)))
 
 
 class Scene:

@@ -98,6 +98,10 @@ void orc_render_sample(const orc_scene* scene, const rt_launch_params* params, u
 uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* params, uint32_t first, uint32_t count,
                            rt_photon* out, uint32_t capacity, int threads);
 
+/* Rays traced by orc_render_sample / orc_trace_photons since the last reset
+ * (for timing the oracle as the CPU baseline). */
+uint64_t orc_ray_counter(int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@
 #include "oracle_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -516,8 +517,11 @@ struct orc_scene : Scene {};
 
 namespace orc {
 
+std::atomic<uint64_t> raysTraced{0};
+
 // trace() of device.cu:388-397 followed by the closest-hit / miss programs.
 rt_hit traceHit(const orc_scene* scene, const float origin[3], const float direction[3], float tmax) {
+    raysTraced.fetch_add(1, std::memory_order_relaxed);
     const float o4[4] = {origin[0], origin[1], origin[2], 0.001f};
     const float d4[4] = {direction[0], direction[1], direction[2], tmax};
     const Best best = traceScene(*scene, o4, d4, true, false);
@@ -535,6 +539,10 @@ const rt_gpu_vertex* geometryVertices(const orc_scene* scene, uint32_t geometry,
 }  // namespace orc
 
 extern "C" {
+
+uint64_t orc_ray_counter(int reset) {
+    return reset ? orc::raysTraced.exchange(0) : orc::raysTraced.load();
+}
 
 orc_scene* orc_scene_create(void) { return new orc_scene(); }
 void orc_scene_destroy(orc_scene* s) { delete s; }

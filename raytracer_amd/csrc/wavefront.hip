@@ -49,7 +49,8 @@ struct Buffers {
     float4* lastOrigin;          // xyz + flags
     float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
     uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length
-    unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers
+    unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
+                                 // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
     rt_photon* photonTemp;       // photon pass: one slot per emission of the batch
     uint32_t* photonFlags;
 };
@@ -81,7 +82,7 @@ __device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t*
 
 // device.cu:882-906: one path per pixel of [pixelBegin, pixelBegin + count)
 __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p, uint32_t pixelBegin, uint32_t count,
-                                                              Buffers b) {
+                                                              uint32_t seedSample, Buffers b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         b.counts[0] = count;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
         return;
     const uint32_t index = pixelBegin + i;
     const uint32_t px = index % p.width, py = index / p.width;
-    uint32_t rng = index * 9781U + p.sample * 6271U + 0x68bc21ebU;
+    uint32_t rng = index * 9781U + seedSample * 6271U + 0x68bc21ebU;
     const float jx = random01(rng);
     const float jy = random01(rng);
     const float sx = (static_cast<float>(px) + jx) / static_cast<float>(p.width);
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
 }
 
 // Closest hit for the first counts[which] rays of a queue (the extend stage).
+// COUNT adds the visited nodes / tested triangles / entered instances to stats[4..6].
+template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void extendKernel(const WideNode* topNodes, const InstanceRecord* instances,
                                                             Buffers b, int which) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
@@ -127,15 +130,29 @@ __global__ __launch_bounds__(kTraceBlock) void extendKernel(const WideNode* topN
     if (blockIdx.x >= blocks)
         return;
     const uint32_t ray = xcdRemap(blockIdx.x, blocks) * kTraceBlock + threadIdx.x;
-    if (ray >= n)
-        return;
-    const float4 o4 = b.rayOrigin[which][ray];
-    const float4 d4 = b.rayDirection[which][ray];
-    TraceCounters unused;
-    const TraceResult r = traceRay<false>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w,
-                                          false, &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x], kTraceBlock, unused);
-    b.hits[ray] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
-    b.hitInstance[ray] = r.instance;
+    TraceCounters local;
+    if (ray < n) {
+        const float4 o4 = b.rayOrigin[which][ray];
+        const float4 d4 = b.rayDirection[which][ray];
+        const TraceResult r =
+            traceRay<COUNT>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, false,
+                            &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x], kTraceBlock, local);
+        b.hits[ray] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
+        b.hitInstance[ray] = r.instance;
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int delta = 32; delta >= 1; delta >>= 1) {
+            local.nodes += __shfl_down(local.nodes, delta, 64);
+            local.triangles += __shfl_down(local.triangles, delta, 64);
+            local.instances += __shfl_down(local.instances, delta, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&b.stats[4], local.nodes);
+            atomicAdd(&b.stats[5], local.triangles);
+            atomicAdd(&b.stats[6], local.instances);
+        }
+    }
 }
 
 // One bounce of device.cu:908-1041 for every path of queue `which`.
@@ -600,8 +617,16 @@ __global__ void photonCountKernel(rt_launch_params p, uint32_t count, const uint
 }  // namespace
 }  // namespace rt
 
+struct StageTiming {
+    int stage;
+    hipEvent_t start, stop;
+};
+
 struct rt_wavefront {
     int device = 0;
+    uint32_t flags = 0;               // RT_WAVEFRONT_TIME_STAGES | RT_WAVEFRONT_COUNT_TRAVERSAL
+    std::vector<StageTiming> timings; // pending event pairs (flag TIME_STAGES)
+    std::vector<hipEvent_t> eventPool;
     rt::Buffers buffers{};
     std::vector<void*> allocations;
     uint32_t* scanCounts = nullptr;    // capacity + 1
@@ -617,6 +642,12 @@ void rt_wavefront_destroy(rt_wavefront* w) {
         return;
     for (void* p : w->allocations)
         (void)hipFree(p);
+    for (auto& t : w->timings) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto e : w->eventPool)
+        (void)hipEventDestroy(e);
     delete w;
 }
 
@@ -662,14 +693,14 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     for (int k = 0; k < 6; ++k)
         allocate(b.sample[k], maxPaths);
     allocate(b.counts, 4);
-    allocate(b.stats, 4);
+    allocate(b.stats, 8);
     allocate(b.photonTemp, maxPaths);
     allocate(b.photonFlags, static_cast<size_t>(maxPaths) + 1);
     allocate(w->scanCounts, static_cast<size_t>(maxPaths) + 1);
     allocate(w->scanPartials, scanScratchEntries(static_cast<size_t>(maxPaths) + 1));
     if (status == RT_SUCCESS) {
         if (hipMemset(b.counts, 0, sizeof(uint32_t) * 4) != hipSuccess ||
-            hipMemset(b.stats, 0, sizeof(unsigned long long) * 4) != hipSuccess)
+            hipMemset(b.stats, 0, sizeof(unsigned long long) * 8) != hipSuccess)
             status = failInvalid("hipMemset (wavefront counters)");
     }
     if (status != RT_SUCCESS) {
@@ -680,16 +711,80 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     return RT_SUCCESS;
 }
 
-rt_status rt_wavefront_stats(rt_wavefront* w, uint64_t* out4, int reset, void* stream) {
-    if (!w || !out4)
+rt_status rt_wavefront_stats(rt_wavefront* w, uint64_t* out8, int reset, void* stream) {
+    if (!w || !out8)
         return failInvalid("null pointer");
     auto s = static_cast<hipStream_t>(stream);
-    RT_HIP(hipMemcpyAsync(out4, w->buffers.stats, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipMemcpyAsync(out8, w->buffers.stats, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, s));
     RT_HIP(hipStreamSynchronize(s));
     if (reset)
-        RT_HIP(hipMemsetAsync(w->buffers.stats, 0, sizeof(uint64_t) * 4, s));
+        RT_HIP(hipMemsetAsync(w->buffers.stats, 0, sizeof(uint64_t) * 8, s));
     return RT_SUCCESS;
 }
+
+rt_status rt_wavefront_configure(rt_wavefront* w, uint32_t flags) {
+    if (!w)
+        return failInvalid("null pointer");
+    w->flags = flags;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_timings(rt_wavefront* w, float* milliseconds5, uint32_t* launches5, void* stream) {
+    if (!w || !milliseconds5 || !launches5)
+        return failInvalid("null pointer");
+    RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    for (int k = 0; k < 5; ++k) {
+        milliseconds5[k] = 0.0f;
+        launches5[k] = 0;
+    }
+    for (auto& t : w->timings) {
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+        milliseconds5[t.stage] += ms;
+        ++launches5[t.stage];
+        w->eventPool.push_back(t.start);
+        w->eventPool.push_back(t.stop);
+    }
+    w->timings.clear();
+    return RT_SUCCESS;
+}
+
+namespace {
+
+// Brackets one launch with events when stage timing is on.
+struct StageTimer {
+    rt_wavefront* w;
+    hipStream_t stream;
+    int stage;
+    hipEvent_t stop = nullptr;
+    StageTimer(rt_wavefront* wavefront, hipStream_t s, int stageIndex) : w(wavefront), stream(s), stage(stageIndex) {
+        if (!(w->flags & RT_WAVEFRONT_TIME_STAGES))
+            return;
+        hipEvent_t start = take();
+        stop = take();
+        if (start && stop) {
+            (void)hipEventRecord(start, stream);
+            w->timings.push_back({stage, start, stop});
+        } else {
+            stop = nullptr;
+        }
+    }
+    ~StageTimer() {
+        if (stop)
+            (void)hipEventRecord(stop, stream);
+    }
+    hipEvent_t take() {
+        if (!w->eventPool.empty()) {
+            hipEvent_t e = w->eventPool.back();
+            w->eventPool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+};
+
+}  // namespace
 
 static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
     if (!w || !params)
@@ -710,6 +805,13 @@ static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* para
 
 rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin, uint32_t pixelEnd,
                            void* stream) {
+    if (!params)
+        return failInvalid("null pointer");
+    return rt_render_sample_seeded(w, params, pixelBegin, pixelEnd, params->sample, stream);
+}
+
+rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin,
+                                  uint32_t pixelEnd, uint32_t seedSample, void* stream) {
     const rt_scene* scene = nullptr;
     RT_TRY(checkLaunch(w, params, scene));
     if (pixelEnd < pixelBegin || pixelEnd > params->width * params->height)
@@ -722,16 +824,38 @@ rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint
     auto s = static_cast<hipStream_t>(stream);
     const Buffers& b = w->buffers;
     const unsigned blocks = divUp(count, kShadeBlock);
-    hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+    const bool counted = w->flags & RT_WAVEFRONT_COUNT_TRAVERSAL;
+    {
+        StageTimer timer(w, s, 0);
+        hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count,
+                           seedSample, b);
+    }
     for (uint32_t depth = 0; depth < params->maxDepth; ++depth) {
         const int which = depth & 1U;
-        hipLaunchKernelGGL(extendKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b, which);
-        hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
-                           scene->hitGroups, b, which, depth);
-        hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b);
+        {
+            StageTimer timer(w, s, 1);
+            if (counted)
+                hipLaunchKernelGGL(extendKernel<true>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                                   scene->instances, b, which);
+            else
+                hipLaunchKernelGGL(extendKernel<false>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                                   scene->instances, b, which);
+        }
+        {
+            StageTimer timer(w, s, 2);
+            hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
+                               scene->hitGroups, b, which, depth);
+        }
+        {
+            StageTimer timer(w, s, 3);
+            hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b);
+        }
         hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
     }
-    hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+    {
+        StageTimer timer(w, s, 4);
+        hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+    }
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }
@@ -753,8 +877,8 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
                            count, b);
         for (uint32_t depth = 0; depth < 10U; ++depth) {
             const int which = depth & 1U;
-            hipLaunchKernelGGL(extendKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b,
-                               which);
+            hipLaunchKernelGGL(extendKernel<false>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                               scene->instances, b, which);
             hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
             hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);

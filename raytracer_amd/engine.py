@@ -65,8 +65,11 @@ SYMBOLS = {
     "rt_wavefront_create": (C.c_int, [_u32, C.POINTER(_vp)]),
     "rt_wavefront_destroy": (None, [_vp]),
     "rt_render_sample": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "rt_render_sample_seeded": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "rt_trace_photons": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
     "rt_wavefront_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
+    "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
+    "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
 }
 
 _lib = None

@@ -198,6 +198,9 @@ uint32_t rth_renderer_samples(rt::Renderer* r) { return r->samples(); }
 int rth_renderer_set_photon_budget(rt::Renderer* r, uint32_t emissions, uint32_t capacity, uint32_t buckets) {
     return guarded([&] { r->setPhotonBudget(emissions, capacity, buckets); });
 }
+int rth_renderer_set_sample_sequence(rt::Renderer* r, uint32_t first, uint32_t stride) {
+    return guarded([&] { r->setSampleSequence(first, stride); });
+}
 int rth_renderer_set_pixel_range(rt::Renderer* r, uint32_t begin, uint32_t end) {
     return guarded([&] { r->setPixelRange(begin, end); });
 }
@@ -218,7 +221,13 @@ void* rth_renderer_accumulation_buffer(rt::Renderer* r, int index) {
     guarded([&] { p = r->accumulationBuffer(index); });
     return p;
 }
-int rth_renderer_statistics(rt::Renderer* r, uint64_t* out4) { return guarded([&] { r->statistics(out4); }); }
+int rth_renderer_statistics(rt::Renderer* r, uint64_t* out8) { return guarded([&] { r->statistics(out8); }); }
+int rth_renderer_set_measurement(rt::Renderer* r, int timeStages, int countTraversal) {
+    return guarded([&] { r->setMeasurement(timeStages != 0, countTraversal != 0); });
+}
+int rth_renderer_stage_timings(rt::Renderer* r, float* milliseconds5, uint32_t* launches5) {
+    return guarded([&] { r->stageTimings(milliseconds5, launches5); });
+}
 int rth_renderer_synchronize(rt::Renderer* r) { return guarded([&] { r->synchronize(); }); }
 void rth_renderer_launch_params(rt::Renderer* r, rt_launch_params* out) { *out = r->launchParams(); }
 float rth_renderer_caustic_radius(rt::Renderer* r) { return r->causticRadius(); }

@@ -557,7 +557,9 @@ struct Renderer::Impl {
         launch.composite = nullptr;
         launch.output = static_cast<rt_uchar4*>(target ? target : output.data());
         launch.sample = sample;
-        engineCheck(rt_render_sample(wavefront, &launch, pixelBegin, pixelEnd, nullptr), "rt_render_sample");
+        engineCheck(rt_render_sample_seeded(wavefront, &launch, pixelBegin, pixelEnd,
+                                            sampleFirst + sample * sampleStride, nullptr),
+                    "rt_render_sample");
         ++sample;
         photonPassPending = true;
     }
@@ -566,6 +568,7 @@ struct Renderer::Impl {
     std::uint32_t height = 0;
     std::uint32_t sample = 0;
     std::uint32_t pixelBegin = 0, pixelEnd = 0;
+    std::uint32_t sampleFirst = 0, sampleStride = 1;
     rt_scene* sceneHandle = nullptr;
     rt_wavefront* wavefront = nullptr;
     std::vector<GeometryState> geometries;
@@ -637,6 +640,12 @@ void Renderer::setPhotonBudget(std::uint32_t emissions, std::uint32_t capacity, 
     impl_->reset();
 }
 
+void Renderer::setSampleSequence(std::uint32_t first, std::uint32_t stride) {
+    impl_->sampleFirst = first;
+    impl_->sampleStride = stride;
+    impl_->reset();
+}
+
 void Renderer::setPixelRange(std::uint32_t begin, std::uint32_t end) {
     if (end < begin || end > impl_->width * impl_->height)
         throw std::runtime_error("pixel range outside the image");
@@ -659,8 +668,16 @@ void* Renderer::accumulationBuffer(int index) const {
         throw std::runtime_error("accumulation buffer index");
     return impl_->aov[index].data();
 }
-void Renderer::statistics(std::uint64_t out[4]) {
+void Renderer::statistics(std::uint64_t out[8]) {
     engineCheck(rt_wavefront_stats(impl_->wavefront, out, 1, nullptr), "rt_wavefront_stats");
+}
+void Renderer::setMeasurement(bool timeStages, bool countTraversal) {
+    engineCheck(rt_wavefront_configure(impl_->wavefront, (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) |
+                                                             (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U)),
+                "rt_wavefront_configure");
+}
+void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
+    engineCheck(rt_wavefront_timings(impl_->wavefront, milliseconds, launches, nullptr), "rt_wavefront_timings");
 }
 void Renderer::synchronize() const { hipCheck(hipDeviceSynchronize()); }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }

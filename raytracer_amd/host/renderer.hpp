@@ -44,6 +44,9 @@ public:
     // Photon map sizes (the reference hard-codes 2^24 emissions, 2^23 stored,
     // 2^22 buckets, src/renderer.cpp:533-535).  Resets the accumulation.
     void setPhotonBudget(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets);
+    // Sample-index sharding: the n-th render() call draws the random streams of
+    // sample index first + n * stride; the running mean still counts local samples.
+    void setSampleSequence(std::uint32_t first, std::uint32_t stride);
     // Restricts render() to the pixels [begin, end) in row-major order.
     void setPixelRange(std::uint32_t begin, std::uint32_t end);
     // Splits a photon pass: render() then no longer runs it by itself; the
@@ -60,8 +63,15 @@ public:
     void finishPhotonPass(std::uint32_t totalPhotons);
     void* accumulationBuffer(int index) const;  // device float4 buffers: 0 accumulation .. 6 normal guide
     // Counters since the last call: [0] extend rays, [1] shadow rays, [2] gather
-    // queries, [3] photons read by gathers.  Waits for the GPU.
-    void statistics(std::uint64_t out[4]);
+    // queries, [3] photons read by gathers, [4] nodes visited, [5] triangles
+    // tested, [6] instances entered (the last three only while traversal counting
+    // is on).  Waits for the GPU.
+    void statistics(std::uint64_t out[8]);
+    // Measurement switches: event-time every stage launch / count traversal steps.
+    void setMeasurement(bool timeStages, bool countTraversal);
+    // Event-timed milliseconds and launch counts per stage since the last call:
+    // generate, extend, shade, shadow, accumulate.  Waits for the GPU.
+    void stageTimings(float milliseconds[5], std::uint32_t launches[5]);
     void synchronize() const;
     const rt_launch_params& launchParams() const;
     float causticRadius() const;

@@ -95,6 +95,7 @@ _SIG = {
     "rth_renderer_linear_pixels": (C.c_int, [_vp, _vp]),
     "rth_renderer_samples": (_u32, [_vp]),
     "rth_renderer_set_photon_budget": (C.c_int, [_vp, _u32, _u32, _u32]),
+    "rth_renderer_set_sample_sequence": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_pixel_range": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
@@ -106,6 +107,8 @@ _SIG = {
     "rth_renderer_finish_photon_pass": (C.c_int, [_vp, _u32]),
     "rth_renderer_accumulation_buffer": (_vp, [_vp, C.c_int]),
     "rth_renderer_statistics": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rth_renderer_set_measurement": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rth_renderer_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rth_renderer_synchronize": (C.c_int, [_vp]),
     "rth_renderer_launch_params": (None, [_vp, C.POINTER(LaunchParams)]),
     "rth_renderer_caustic_radius": (_f32, [_vp]),
@@ -250,6 +253,9 @@ class Renderer:
     def set_photon_budget(self, emissions, capacity, buckets):
         _check(load().rth_renderer_set_photon_budget(self.handle, emissions, capacity, buckets))
 
+    def set_sample_sequence(self, first, stride):
+        _check(load().rth_renderer_set_sample_sequence(self.handle, first, stride))
+
     def set_pixel_range(self, begin, end):
         _check(load().rth_renderer_set_pixel_range(self.handle, begin, end))
 
@@ -283,9 +289,21 @@ class Renderer:
         return int(load().rth_renderer_accumulation_buffer(self.handle, index) or 0)
 
     def statistics(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _check(load().rth_renderer_statistics(self.handle, out))
-        return dict(extend_rays=out[0], shadow_rays=out[1], gather_queries=out[2], gathered_photons=out[3])
+        return dict(extend_rays=out[0], shadow_rays=out[1], gather_queries=out[2], gathered_photons=out[3],
+                    nodes=out[4], triangles=out[5], instances=out[6])
+
+    def set_measurement(self, time_stages=False, count_traversal=False):
+        _check(load().rth_renderer_set_measurement(self.handle, int(time_stages), int(count_traversal)))
+
+    def stage_timings(self):
+        """{stage: (milliseconds, launches)} of the event-timed launches since the last call."""
+        ms = (C.c_float * 5)()
+        n = (C.c_uint32 * 5)()
+        _check(load().rth_renderer_stage_timings(self.handle, ms, n))
+        names = ("generate", "extend", "shade", "shadow", "accumulate")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def synchronize(self):
         _check(load().rth_renderer_synchronize(self.handle))
