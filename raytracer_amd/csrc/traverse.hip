@@ -9,7 +9,7 @@ namespace rt {
 namespace {
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void traceKernel(const WideNode* topNodes, const InstanceRecord* instances,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(const WideNode* topNodes, const InstanceRecord* instances,
                                                            const float4* originTmin, const float4* directionTmax,
                                                            uint32_t n, uint4* hits, uint32_t* instanceOut,
                                                            uint8_t* occluded, unsigned long long* counters) {
@@ -24,8 +24,8 @@ __global__ __launch_bounds__(kTraceBlock) void traceKernel(const WideNode* topNo
         const float4 o4 = originTmin[ray];
         const float4 d4 = directionTmax[ray];
         const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
-        const TraceResult r = traceRay<COUNT>(topNodes, instances, world, o4.w, d4.w, ANY, &stackRef[0][threadIdx.x],
-                                              &stackT[0][threadIdx.x], kTraceBlock, local);
+        const TraceResult r = traceRay<COUNT>(topNodes, instances, world, o4.w, d4.w, kNoHit, kNoHit, ANY,
+                                              ldsView(&stackRef[0][threadIdx.x]), ldsView(&stackT[0][threadIdx.x]), kTraceBlock, local);
         const bool found = r.primitive != kNoHit;
         if (ANY) {
             occluded[ray] = found ? 1 : 0;

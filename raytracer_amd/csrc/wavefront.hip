@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
 // Closest hit for the first counts[which] rays of a queue (the extend stage).
 // COUNT adds the visited nodes / tested triangles / entered instances to stats[4..6].
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void extendKernel(const WideNode* topNodes, const InstanceRecord* instances,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void extendKernel(const WideNode* topNodes, const InstanceRecord* instances,
                                                             Buffers b, int which) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(kTraceBlock) void extendKernel(const WideNode* topN
         const float4 o4 = b.rayOrigin[which][ray];
         const float4 d4 = b.rayDirection[which][ray];
         const TraceResult r =
-            traceRay<COUNT>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, false,
-                            &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x], kTraceBlock, local);
+            traceRay<COUNT>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit,
+                            false, ldsView(&stackRef[0][threadIdx.x]), ldsView(&stackT[0][threadIdx.x]), kTraceBlock, local);
         b.hits[ray] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
         b.hitInstance[ray] = r.instance;
     }
@@ -356,8 +356,15 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
 // visible(), device.cu:548-559: the light is seen when nothing is hit before
 // it (delta lights, environment) or when the closest hit is the sampled
 // emissive triangle itself; then the deferred contribution is added.
-__global__ __launch_bounds__(kTraceBlock) void shadowKernel(const WideNode* topNodes, const InstanceRecord* instances,
-                                                            Buffers b) {
+//
+// "The closest hit is that triangle" is decided without a closest-hit walk: the
+// ray is intersected with the sampled triangle first (same arithmetic as the
+// traversal, so the same t), and the scene is then searched for ANY hit that
+// beats (t, instance, primitive) of that candidate - the first one found ends
+// the walk.  The outcome is the same bit for bit.
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void shadowKernel(const WideNode* topNodes, const InstanceRecord* instances,
+                                                            const ShadeInstance* shadeInstances,
+                                                            const rt_hit_group_data* geometries, Buffers b) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
     const uint32_t n = b.counts[2];
@@ -372,17 +379,44 @@ __global__ __launch_bounds__(kTraceBlock) void shadowKernel(const WideNode* topN
     const float4 c4 = b.shadowContribution[ray];
     const uint32_t bits = __float_as_uint(c4.w);
     const bool needsTriangle = bits & 4U;
-    TraceCounters unused;
-    const TraceResult r = traceRay<false>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w,
-                                          !needsTriangle, &stackRef[0][threadIdx.x], &stackT[0][threadIdx.x],
-                                          kTraceBlock, unused);
-    const bool found = r.primitive != kNoHit;
-    bool seen;
+    const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
+    float limit = d4.w;
+    uint32_t candidateInstance = kNoHit, candidatePrimitive = kNoHit;
+    bool possible = true;
     if (needsTriangle) {
         const uint2 target = b.shadowTarget[ray];
-        seen = found && r.instance == target.x && r.primitive == target.y;
-    } else {
-        seen = !found;
+        const ShadeInstance& record = shadeInstances[target.x];
+        const rt_hit_group_data geometry = geometries[record.geometry];
+        const rt_uint3 triangle = geometry.indices[target.y];
+        const rt_float3 a = geometry.vertices[triangle.x].position;
+        const rt_float3 bb = geometry.vertices[triangle.y].position;
+        const rt_float3 c = geometry.vertices[triangle.z].position;
+        const float* m = record.toObject;
+        Ray local;
+        local.ox = ((m[0] * world.ox + m[1] * world.oy) + m[2] * world.oz) + m[3];
+        local.oy = ((m[4] * world.ox + m[5] * world.oy) + m[6] * world.oz) + m[7];
+        local.oz = ((m[8] * world.ox + m[9] * world.oy) + m[10] * world.oz) + m[11];
+        local.dx = (m[0] * world.dx + m[1] * world.dy) + m[2] * world.dz;
+        local.dy = (m[4] * world.dx + m[5] * world.dy) + m[6] * world.dz;
+        local.dz = (m[8] * world.dx + m[9] * world.dy) + m[10] * world.dz;
+        const Shear shear = makeShear(local);
+        float t, u, v;
+        possible = intersectTriangle(local, shear,
+                                     make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), 0U),
+                                     make_uint4(__float_as_uint(bb.x), __float_as_uint(bb.y), __float_as_uint(bb.z), 0U),
+                                     make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0U),
+                                     o4.w, limit, t, u, v);
+        limit = t;
+        candidateInstance = target.x;
+        candidatePrimitive = target.y;
+    }
+    bool seen = false;
+    if (possible) {
+        TraceCounters unused;
+        const TraceResult r = traceRay<false>(topNodes, instances, world, o4.w, limit, candidateInstance,
+                                              candidatePrimitive, true, ldsView(&stackRef[0][threadIdx.x]),
+                                              ldsView(&stackT[0][threadIdx.x]), kTraceBlock, unused);
+        seen = r.primitive == kNoHit;  // nothing in front of the light (or of the sampled triangle)
     }
     if (seen) {
         const uint32_t path = b.shadowPath[ray];
@@ -848,7 +882,8 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
         }
         {
             StageTimer timer(w, s, 3);
-            hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances, b);
+            hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
+                               scene->shadeInstances, scene->hitGroups, b);
         }
         hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
     }
