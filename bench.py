@@ -4,9 +4,10 @@
 One "step" is one pass of the hot path over one frame of synthetic input: one camera sample per
 pixel of the Dragon-Cornell stand-in (a ~870k-triangle absorbing-glass mesh in a Cornell box with an
 emissive panel) at 1920x1080, preview profile (5 bounces), through rt::Renderer::render(): generate,
-then per bounce extend (closest hit) / shade / shadow, then accumulate.  Scene, BVH and every buffer
-are resident in HBM before the timed region.  The headline value is rays traced (extend + shadow)
-per second over the whole step; the extend kernel's share is priced against the HBM roofline.
+then per bounce trace / shade (the shadow rays of a bounce ride in the same persistent launch as the
+closest-hit rays of the next), then accumulate.  Scene, BVH and every buffer are resident in HBM
+before the timed region.  The headline value is rays traced (closest-hit + shadow) per second over
+the whole step; the trace kernel's share is priced against the HBM roofline.
 
 After the timed steps the photon map of the reference's size (2^23 photons, 2^22 buckets) is built
 and gathered once per step count for the second metric (photon gathers/s, grid build time).
@@ -168,8 +169,9 @@ def main():
     renderer.set_measurement(count_traversal=True)
     renderer.render()
     c = renderer.statistics()
-    nodes_per_ray = c["nodes"] / max(c["extend_rays"], 1)
-    tris_per_ray = c["triangles"] / max(c["extend_rays"], 1)
+    counted_rays = max(c["extend_rays"] + c["shadow_rays"], 1)
+    nodes_per_ray = c["nodes"] / counted_rays
+    tris_per_ray = c["triangles"] / counted_rays
     bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
     renderer.set_measurement(time_stages=False)
@@ -212,8 +214,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    extend_ms, extend_launches = stages["extend"]
-    achieved = stats["extend_rays"] * bytes_per_ray / (extend_ms * 1e-3) / 1e9
+    trace_ms, trace_launches = stages["trace"]
+    achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
     p = renderer.launch_params()
     out = {
         "metric": "closest_hit_mrays_per_s",
@@ -231,7 +233,7 @@ def main():
         "config": {
             "workload": f"{args.workload} stand-in, {args.width}x{args.height}, 1 sample per pixel per step, "
                         f"{'final (32 bounces, photon map)' if profile else 'preview (5 bounces)'}, wavefront "
-                        f"generate/extend/shade/shadow/accumulate through rt::Renderer::render()",
+                        f"generate/trace/shade/accumulate through rt::Renderer::render()",
             "rays_per_step_per_gpu": rays / args.steps,
             "extend_rays_per_step": stats["extend_rays"] / args.steps,
             "shadow_rays_per_step": stats["shadow_rays"] / args.steps,
@@ -241,12 +243,11 @@ def main():
             "parallelism": f"replicated scene, {world} x sample-index shards, no data-path collective",
         },
         "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
-        "extend_kernel_mrays_per_s": stats["extend_rays"] / (extend_ms * 1e-3) / 1e6,
-        "shadow_kernel_mrays_per_s": stats["shadow_rays"] / max(stages["shadow"][0] * 1e-3, 1e-9) / 1e6,
+        "trace_kernel_mrays_per_s": rays / (trace_ms * 1e-3) / 1e6,
         "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {
             "bound": "hbm",
-            "kernel": "extendKernel (closest hit)",
+            "kernel": "traceKernel (closest-hit and shadow rays of a bounce)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -255,8 +256,8 @@ def main():
             "bytes_per_ray": bytes_per_ray,
             "nodes_per_ray": nodes_per_ray,
             "triangles_per_ray": tris_per_ray,
-            "avg_launch_ms": extend_ms / max(extend_launches, 1),
-            "launches": extend_launches,
+            "avg_launch_ms": trace_ms / max(trace_launches, 1),
+            "launches": trace_launches,
         },
     }
     if photon is not None:

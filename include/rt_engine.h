@@ -203,19 +203,24 @@ rt_status rt_render_sample_seeded(rt_wavefront* wavefront, const rt_launch_param
 rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
                            uint32_t emissionCount, void* stream);
 
-/* Copies the running counters to out8 (host): [0] rays through the extend
- * stage, [1] shadow rays, [2] caustic gather queries, [3] photons read by them,
- * [4] wide nodes visited, [5] triangles tested, [6] instances entered by extend
- * launches made while RT_WAVEFRONT_COUNT_TRAVERSAL was set, [7] unused.
+/* Copies the running counters to out8 (host): [0] closest-hit (extend) rays,
+ * [1] shadow rays, [2] caustic gather queries, [3] photons read by them,
+ * [4] wide nodes visited, [5] triangles tested, [6] instances entered by the
+ * ray launches (both kinds of ray) made while RT_WAVEFRONT_COUNT_TRAVERSAL was
+ * set, [7] node / triangle / instance references the ray stage refused because
+ * they pointed outside their array (0 unless the acceleration structure is
+ * damaged; such a ray ends as a miss instead of faulting).
  * Synchronises `stream`; reset != 0 zeroes the counters afterwards. */
 rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out8, int reset, void* stream);
 
 /* Measurement switches (both off by default). */
 #define RT_WAVEFRONT_TIME_STAGES 1u      /* bracket every stage launch of rt_render_sample with HIP events */
-#define RT_WAVEFRONT_COUNT_TRAVERSAL 2u  /* extend launches count visited nodes / tested triangles */
+#define RT_WAVEFRONT_COUNT_TRAVERSAL 2u  /* ray launches count visited nodes / tested triangles */
 rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
 /* Sums the event-timed launches since the last call per stage: [0] generate,
- * [1] extend, [2] shade, [3] shadow, [4] accumulate.  Synchronises `stream`. */
+ * [1] trace (the shadow rays of a bounce and the closest-hit rays of the next
+ * share one launch), [2] shade, [3] queue bookkeeping between bounces,
+ * [4] accumulate.  Synchronises `stream`. */
 rt_status rt_wavefront_timings(rt_wavefront* wavefront, float* milliseconds5, uint32_t* launches5, void* stream);
 
 #ifdef __cplusplus

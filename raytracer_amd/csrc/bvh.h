@@ -7,11 +7,15 @@
 
 #include "common.h"
 
+#include <atomic>
 #include <vector>
 
 namespace rt {
 
 constexpr int kWide = 8;          // children per node
+constexpr int kFeedStride = 32;   // words between the per-XCD cursors of a persistent ray feed
+constexpr int kFeedWords = 8 * kFeedStride;
+constexpr int kFeedSlots = 16;    // cursor sets a scene keeps for overlapping batched queries
 constexpr int kMaxLeaf = 4;       // triangles per leaf child
 constexpr uint32_t kNoHit = 0xffffffffU;
 
@@ -51,7 +55,8 @@ struct alignas(16) InstanceRecord {
     const PackedTriangle* triangles;
     uint32_t instanceId;
     uint32_t geometry;
-    uint32_t pad[2];
+    uint32_t nodeCount;           // entries of `nodes` / `triangles`: the traversal checks references against them
+    uint32_t triangleCount;
 };
 static_assert(sizeof(InstanceRecord) == 80, "instance record is 80 bytes");
 
@@ -96,4 +101,6 @@ struct rt_scene {
     uint32_t hitGroupCount = 0;
     std::vector<float> inverses;            // 12 floats per instance (host copy)
     float buildMilliseconds = 0.0f;
+    uint32_t* feedCursors = nullptr;        // kFeedSlots sets of ray-feed cursors for the batched queries
+    mutable std::atomic<uint32_t> feedNext{0};
 };

@@ -757,6 +757,8 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
         r.triangles = d.blas->triangles;
         r.instanceId = d.instanceId;
         r.geometry = d.geometry;
+        r.nodeCount = static_cast<uint32_t>(d.blas->nodeCount);
+        r.triangleCount = static_cast<uint32_t>(d.blas->triangleCount);
         boxes[i] = instanceBox(d.transform, d.blas->bounds);
         scene->blasNodes += d.blas->nodeCount;
         scene->triangles += d.blas->triangleCount;
@@ -775,6 +777,7 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     scene->depth = builder.depth;
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->nodes), sizeof(WideNode) * builder.nodes.size()));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * count));
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->feedCursors), sizeof(uint32_t) * kFeedWords * kFeedSlots));
     RT_HIP(hipMemcpyAsync(scene->nodes, builder.nodes.data(), sizeof(WideNode) * builder.nodes.size(),
                           hipMemcpyHostToDevice, stream));
     RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice,
@@ -865,6 +868,8 @@ void rt_scene_destroy(rt_scene* scene) {
         (void)hipFree(scene->nodes);
     if (scene->instances)
         (void)hipFree(scene->instances);
+    if (scene->feedCursors)
+        (void)hipFree(scene->feedCursors);
     if (scene->shadeInstances)
         (void)hipFree(scene->shadeInstances);
     if (scene->hitGroups)

@@ -1,44 +1,53 @@
 // Ray-query kernels: closest hit and any hit over a batch of rays.
 //
 // Replaces the optixTrace call of the reference (device.cu:388-397) and the
-// occlusion use of it in visible() (device.cu:548-559).  One ray per lane; the
-// traversal itself lives in traverse_core.h.
+// occlusion use of it in visible() (device.cu:548-559).  Persistent waves, one
+// ray per lane at a time; the traversal itself lives in traverse_core.h.
 #include "traverse_core.h"
+
+#include <algorithm>
 
 namespace rt {
 namespace {
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(const WideNode* topNodes, const InstanceRecord* instances,
-                                                           const float4* originTmin, const float4* directionTmax,
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(const WideNode* topNodes, uint32_t topCount, const InstanceRecord* instances,
+                                                           uint32_t instanceCount, const float4* originTmin, const float4* directionTmax,
                                                            uint32_t n, uint4* hits, uint32_t* instanceOut,
-                                                           uint8_t* occluded, unsigned long long* counters) {
+                                                           uint8_t* occluded, unsigned long long* counters,
+                                                           uint32_t* cursors) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
 
-    const uint32_t ray = xcdRemap(blockIdx.x, gridDim.x) * kTraceBlock + threadIdx.x;
-    const bool active = ray < n;
-    TraceCounters local;
-
-    if (active) {
-        const float4 o4 = originTmin[ray];
-        const float4 d4 = directionTmax[ray];
-        const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
-        const TraceResult r = traceRay<COUNT>(topNodes, instances, world, o4.w, d4.w, kNoHit, kNoHit, ANY,
-                                              ldsView(&stackRef[0][threadIdx.x]), ldsView(&stackT[0][threadIdx.x]), kTraceBlock, local);
-        const bool found = r.primitive != kNoHit;
-        if (ANY) {
-            occluded[ray] = found ? 1 : 0;
-        } else {
-            hits[ray] = make_uint4(__float_as_uint(found ? r.t : -1.0f), __float_as_uint(found ? r.u : 0.0f),
-                                   __float_as_uint(found ? r.v : 0.0f), r.primitive);
-            instanceOut[ray] = r.instance;
-        }
-    }
+    uint32_t spillRef[kPrivateStack];
+    float spillT[kPrivateStack];
+    Traversal<COUNT> walk(topNodes, topCount, instances, instanceCount, ldsView(&stackRef[0][threadIdx.x]),
+                          ldsView(&stackT[0][threadIdx.x]), kTraceBlock, spillRef, spillT);
+    RayFeed feed(cursors, n);
+    unsigned long long rays = 0;
+    tracePersistent<COUNT>(
+        walk, feed,
+        [&](uint32_t ray, Traversal<COUNT>& w) {
+            const float4 o4 = originTmin[ray];
+            const float4 d4 = directionTmax[ray];
+            w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit, ANY);
+            ++rays;
+            return true;
+        },
+        [&](uint32_t ray, const TraceResult& r) {
+            const bool found = r.primitive != kNoHit;
+            if (ANY) {
+                occluded[ray] = found ? 1 : 0;
+            } else {
+                hits[ray] = make_uint4(__float_as_uint(found ? r.t : -1.0f), __float_as_uint(found ? r.u : 0.0f),
+                                       __float_as_uint(found ? r.v : 0.0f), r.primitive);
+                instanceOut[ray] = r.instance;
+            }
+        });
 
     if (COUNT) {
         // wave sums first, then one atomic per wave and counter
-        unsigned long long rays = active ? 1ULL : 0ULL;
+        TraceCounters local = walk.counters;
 #pragma unroll
         for (int delta = 32; delta >= 1; delta >>= 1) {
             rays += __shfl_down(rays, delta, 64);
@@ -53,6 +62,31 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
             atomicAdd(&counters[3], local.instances);
         }
     }
+}
+
+// A zeroed set of feed cursors for one launch on `stream`.  The scene owns a
+// small ring of sets, so a few launches on different streams may overlap.
+rt_status feedCursors(const rt_scene* scene, hipStream_t stream, uint32_t** cursors) {
+    const uint32_t slot = scene->feedNext.fetch_add(1U, std::memory_order_relaxed) % kFeedSlots;
+    *cursors = scene->feedCursors + slot * kFeedWords;
+    RT_HIP(hipMemsetAsync(*cursors, 0, kFeedWords * sizeof(uint32_t), stream));
+    return RT_SUCCESS;
+}
+
+template <bool ANY, bool COUNT>
+rt_status launchTrace(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax, uint32_t n,
+                      rt_ray_hit* hits, uint32_t* instance, uint8_t* occluded, uint64_t* counters4, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t* cursors = nullptr;
+    RT_TRY(feedCursors(scene, s, &cursors));
+    const uint32_t blocks = std::min<uint32_t>(divUp(n, kTraceBlock), persistentBlocks(scene->device));
+    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                       static_cast<uint32_t>(scene->nodeCount), scene->instances, scene->instanceCount,
+                       reinterpret_cast<const float4*>(originTmin), reinterpret_cast<const float4*>(directionTmax), n,
+                       reinterpret_cast<uint4*>(hits), instance, occluded,
+                       reinterpret_cast<unsigned long long*>(counters4), cursors);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
 }
 
 rt_status checkScene(const rt_scene* scene) {
@@ -85,12 +119,7 @@ rt_status rt_trace_closest(const rt_scene* scene, const rt_float4* originTmin, c
         return RT_SUCCESS;
     if (!originTmin || !directionTmax || !hits || !instance)
         return failInvalid("null pointer");
-    hipLaunchKernelGGL((traceKernel<false, false>), dim3(divUp(n, kTraceBlock)), dim3(kTraceBlock), 0,
-                       static_cast<hipStream_t>(stream), scene->nodes, scene->instances,
-                       reinterpret_cast<const float4*>(originTmin), reinterpret_cast<const float4*>(directionTmax), n,
-                       reinterpret_cast<uint4*>(hits), instance, nullptr, nullptr);
-    RT_HIP(hipGetLastError());
-    return RT_SUCCESS;
+    return launchTrace<false, false>(scene, originTmin, directionTmax, n, hits, instance, nullptr, nullptr, stream);
 }
 
 rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* originTmin,
@@ -101,13 +130,7 @@ rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* origi
         return RT_SUCCESS;
     if (!originTmin || !directionTmax || !hits || !instance || !counters4)
         return failInvalid("null pointer");
-    hipLaunchKernelGGL((traceKernel<false, true>), dim3(divUp(n, kTraceBlock)), dim3(kTraceBlock), 0,
-                       static_cast<hipStream_t>(stream), scene->nodes, scene->instances,
-                       reinterpret_cast<const float4*>(originTmin), reinterpret_cast<const float4*>(directionTmax), n,
-                       reinterpret_cast<uint4*>(hits), instance, nullptr,
-                       reinterpret_cast<unsigned long long*>(counters4));
-    RT_HIP(hipGetLastError());
-    return RT_SUCCESS;
+    return launchTrace<false, true>(scene, originTmin, directionTmax, n, hits, instance, nullptr, counters4, stream);
 }
 
 rt_status rt_trace_any(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax, uint32_t n,
@@ -117,12 +140,7 @@ rt_status rt_trace_any(const rt_scene* scene, const rt_float4* originTmin, const
         return RT_SUCCESS;
     if (!originTmin || !directionTmax || !occluded)
         return failInvalid("null pointer");
-    hipLaunchKernelGGL((traceKernel<true, false>), dim3(divUp(n, kTraceBlock)), dim3(kTraceBlock), 0,
-                       static_cast<hipStream_t>(stream), scene->nodes, scene->instances,
-                       reinterpret_cast<const float4*>(originTmin), reinterpret_cast<const float4*>(directionTmax), n,
-                       nullptr, nullptr, occluded, nullptr);
-    RT_HIP(hipGetLastError());
-    return RT_SUCCESS;
+    return launchTrace<true, false>(scene, originTmin, directionTmax, n, nullptr, nullptr, occluded, nullptr, stream);
 }
 
 }  // extern "C"

@@ -1,7 +1,8 @@
 // Per-lane traversal of the two-level 8-wide BVH, shared by every kernel that traces rays.
 //
 // Replaces the optixTrace call of the reference (device.cu:388-397) and the
-// occlusion use of it in visible() (device.cu:548-559).  One ray per lane; the
+// occlusion use of it in visible() (device.cu:548-559).  One ray per lane at a
+// time, in persistent waves that hand a lane a new ray when its ray is done; the
 // traversal stack's first entries live in LDS (one column per lane, so a wave's
 // accesses never share a bank), the rest in private memory; entries carry the
 // child's entry distance so a subtree that fell behind the current hit is
@@ -26,15 +27,29 @@
 
 #include "bvh.h"
 
+#include <atomic>
+
 namespace rt {
 
 // Tuning knobs (compile-time): minimum waves per SIMD the register allocator must
 // leave room for, and whether children are pushed in distance order.
 #ifndef RT_TRACE_MIN_WAVES
-#define RT_TRACE_MIN_WAVES 6
+#define RT_TRACE_MIN_WAVES 5
 #endif
 #ifndef RT_TRACE_SORTED_PUSH
 #define RT_TRACE_SORTED_PUSH 1
+#endif
+// Persistent launches: wide nodes a lane may walk per turn before its leaf, and
+// how many idle lanes make a wave fetch new rays.
+#ifndef RT_TRACE_NODE_STEPS
+#define RT_TRACE_NODE_STEPS 3
+#endif
+#ifndef RT_TRACE_REFILL
+#define RT_TRACE_REFILL 24
+#endif
+// Workgroups launched per resident workgroup slot (1 = exactly one resident set).
+#ifndef RT_TRACE_GRID_SCALE
+#define RT_TRACE_GRID_SCALE 1
 #endif
 
 constexpr int kTraceBlock = 256;
@@ -167,38 +182,146 @@ __device__ inline LdsFloat ldsView(float* p) { return (LdsFloat)p; }
 
 constexpr uint32_t kDone = 0xffffffffU;  // "no more work" reference (has the leaf bit set)
 
-// Traces one ray.  stackRef / stackT point at this lane's column of two LDS
-// arrays of kLdsStack rows and `stride` columns.  With anyHit the walk stops at
-// the first accepted triangle (the result then only says hit or miss).  A hit
-// is accepted when it beats (tmax, initInstance, initPrimitive) in the order
-// (t, instance, primitive); callers without a prior candidate pass kNoHit ids.
+// Development aid (-DRT_TRACE_PROFILE): per code site, how many times a wave
+// issued it and with how many lanes, summed over every traversal kernel.
+#ifdef RT_TRACE_PROFILE
+static __device__ float gTraceProfile[64];  // one copy per translation unit
+static __device__ unsigned int gTraceHistogram[64];  // per kernel: rays by log2(steps), 16 bins
+#define RT_SITE(k)                                                             \
+    do {                                                                       \
+        if ((k) == 0 || (k) == 3)                                              \
+            ++raySteps;                                                        \
+        const float lanes = static_cast<float>(__popcll(__ballot(true)));      \
+        profile[2 * (k)] += 1.0f / lanes;                                      \
+        profile[2 * (k) + 1] += 1.0f;                                          \
+    } while (0)
+#else
+#define RT_SITE(k) ((void)0)
+#endif
+
+// Every index the walk takes out of memory (node, instance and triangle
+// references) is checked against the size of the array it points into before
+// it is used; a reference that fails ends the ray as a miss and is counted in
+// `violations`, so a damaged acceleration structure shows up as a number
+// instead of a memory fault.
+#define RT_GUARD(ok)                                                           \
+    do {                                                                       \
+        if (!(ok)) {                                                           \
+            ++violations;                                                      \
+            found = false;                                                     \
+            node = kDone;                                                      \
+            return;                                                            \
+        }                                                                      \
+    } while (0)
+
+// Traversal state of one lane.  The walk is resumable: begin() takes a ray and
+// nodeStep() / enterInstance() / triangleStep() each do one unit of work and
+// leave the next reference in `node` (kDone when the ray is finished).  That lets a wave hand a new ray to a lane whose ray ended early instead of
+// idling it until the slowest ray of the wave is done (see RayFeed below).
 //
-// Shape of the loop: an inner loop walks wide nodes until the lane holds a leaf,
-// then the leaf is processed; the lanes of a wave therefore run the node code
-// together and the triangle code together instead of alternating per step.
+// stackRef / stackT point at this lane's column of two LDS arrays of kLdsStack
+// rows and `stride` columns; deeper entries spill to private memory.  With anyHit
+// (per ray) the walk stops at the first accepted triangle (the result then only says hit
+// or miss).  A hit is accepted when it beats (tmax, initInstance, initPrimitive)
+// in the order (t, instance, primitive); callers without a prior candidate pass
+// kNoHit ids.
 template <bool COUNT>
-__device__ inline TraceResult traceRay(const WideNode* __restrict__ topNodes,
-                                       const InstanceRecord* __restrict__ instances, const Ray& world, float tmin,
-                                       float tmax, uint32_t initInstance, uint32_t initPrimitive, bool anyHit,
-                                       LdsUint stackRef, LdsFloat stackT, int stride, TraceCounters& counters) {
-    uint32_t privateRef[kPrivateStack];
-    float privateT[kPrivateStack];
-    float bestT = tmax, bestU = 0.0f, bestV = 0.0f;
-    uint32_t bestPrim = initPrimitive, bestInst = initInstance;
-    bool found = false;
+struct Traversal {
+    static constexpr float kShrink = 1.0f - 0x1p-20f, kGrow = 1.0f + 0x1p-20f;
 
-    constexpr float kShrink = 1.0f - 0x1p-20f, kGrow = 1.0f + 0x1p-20f;
-    Ray cur = world;
-    Shear shear{};
-    float idx = __builtin_amdgcn_rcpf(cur.dx), idy = __builtin_amdgcn_rcpf(cur.dy), idz = __builtin_amdgcn_rcpf(cur.dz);
-    const WideNode* nodes = topNodes;
-    const PackedTriangle* triangles = nullptr;
-    uint32_t instanceId = kNoHit;
-    bool inBottom = false;
-    const float tminShrunk = tmin * kShrink;
+    const WideNode* topNodes;
+    const InstanceRecord* instances;
+    LdsUint stackRef;
+    LdsFloat stackT;
+    int stride;
 
-    int sp = 0;
-    auto push = [&](uint32_t ref, float t) {
+    Ray world, cur;
+    Shear shear;
+    float idx, idy, idz;
+    const WideNode* nodes;
+    const PackedTriangle* triangles;
+    uint32_t instanceId;
+    bool inBottom, found, anyHit;
+    float tmin, tminShrunk, tmax;
+    float bestT, bestU, bestV;
+    uint32_t bestPrim, bestInst;
+    int sp;
+    uint32_t node;
+    // overflow stack: arrays owned by the kernel (kept out of this struct so that
+    // the rest of the state is promoted to registers)
+    uint32_t (&privateRef)[kPrivateStack];
+    float (&privateT)[kPrivateStack];
+    TraceCounters counters;
+    uint32_t topNodeLimit, instanceLimit;  // sizes of the top-level arrays
+    uint32_t nodeLimit, triangleLimit;     // sizes of the arrays of the instance the ray is in
+    uint32_t violations;
+#ifdef RT_TRACE_PROFILE
+    float profile[16] = {};
+    int profileBase = 0;
+    uint32_t raySteps = 0;
+    __device__ void finishRay() {
+        const int bin = raySteps ? min(31 - __clz(static_cast<int>(raySteps)), 15) : 0;
+        atomicAdd(&gTraceHistogram[profileBase + bin], 1U);
+        raySteps = 0;
+    }
+    __device__ void flushProfile() {
+        for (int k = 0; k < 16; ++k) {
+            float v = profile[k];
+            for (int delta = 32; delta >= 1; delta >>= 1)
+                v += __shfl_down(v, delta, 64);
+            if ((threadIdx.x & 63) == 0)
+                atomicAdd(&gTraceProfile[profileBase + k], v);
+        }
+    }
+#endif
+
+    // topCount / instanceCount: entries of `top` and `inst`.  Every member starts defined.
+    __device__ __forceinline__ Traversal(const WideNode* top, uint32_t topCount, const InstanceRecord* inst,
+                                         uint32_t instanceCount, LdsUint refs, LdsFloat ts, int s,
+                                         uint32_t (&spillRef)[kPrivateStack], float (&spillT)[kPrivateStack])
+        : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, idx(0.0f),
+          idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), inBottom(false), found(false),
+          anyHit(false), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
+          bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
+          topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(0), triangleLimit(0), violations(0) {}
+
+    __device__ __forceinline__ void begin(const Ray& ray, float rayTmin, float rayTmax, uint32_t initInstance,
+                                          uint32_t initPrimitive, bool stopAtFirstHit) {
+        anyHit = stopAtFirstHit;
+        world = ray;
+        cur = ray;
+        shear = Shear{};
+        idx = __builtin_amdgcn_rcpf(cur.dx);
+        idy = __builtin_amdgcn_rcpf(cur.dy);
+        idz = __builtin_amdgcn_rcpf(cur.dz);
+        nodes = topNodes;
+        triangles = nullptr;
+        instanceId = kNoHit;
+        inBottom = false;
+        found = false;
+        tmin = rayTmin;
+        tminShrunk = rayTmin * kShrink;
+        tmax = rayTmax;
+        bestT = rayTmax;
+        bestU = 0.0f;
+        bestV = 0.0f;
+        bestPrim = initPrimitive;
+        bestInst = initInstance;
+        sp = 0;
+        node = 0;  // the top-level root
+    }
+
+    __device__ __forceinline__ TraceResult result() const {
+        TraceResult r;
+        r.t = found ? bestT : tmax;
+        r.u = found ? bestU : 0.0f;
+        r.v = found ? bestV : 0.0f;
+        r.primitive = found ? bestPrim : kNoHit;
+        r.instance = found ? bestInst : kNoHit;
+        return r;
+    }
+
+    __device__ __forceinline__ void push(uint32_t ref, float t) {
         if (sp < kLdsStack) {
             stackRef[sp * stride] = ref;
             stackT[sp * stride] = t;
@@ -207,11 +330,13 @@ __device__ inline TraceResult traceRay(const WideNode* __restrict__ topNodes,
             privateT[sp - kLdsStack] = t;
         }
         ++sp;
-    };
+    }
+
     // Next entry that can still matter, or kDone.  Leaving an instance restores
     // the world-space ray.
-    auto pop = [&]() -> uint32_t {
+    __device__ __forceinline__ uint32_t pop() {
         for (;;) {
+            RT_SITE(2);
             if (sp == 0)
                 return kDone;
             --sp;
@@ -239,167 +364,291 @@ __device__ inline TraceResult traceRay(const WideNode* __restrict__ topNodes,
                 continue;  // fell behind the closest hit found since
             return ref;
         }
-    };
+    }
 
-    uint32_t node = 0;  // current reference; the top-level root is node 0
-    for (;;) {
-        // ---- wide nodes, until this lane holds a leaf ----
-        while (!(node & kLeafBit)) {
-            if (COUNT)
-                ++counters.nodes;
-            GlobalUint4 np = globalView(nodes + node);
-            const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            const uint32_t imask = n0.w >> 24;
-            // child plane distance = q * a + b per axis; the near planes are shrunk
-            // and the far planes grown by 2^-20 relative, so rounding never rejects
-            // a box whose triangle the intersection test accepts
-            const float ax = __uint_as_float((n0.w & 0xffU) << 23) * idx;
-            const float ay = __uint_as_float(((n0.w >> 8) & 0xffU) << 23) * idy;
-            const float az = __uint_as_float(((n0.w >> 16) & 0xffU) << 23) * idz;
-            const float bx = (__uint_as_float(n0.x) - cur.ox) * idx;
-            const float by = (__uint_as_float(n0.y) - cur.oy) * idy;
-            const float bz = (__uint_as_float(n0.z) - cur.oz) * idz;
-            const float axn = ax * kShrink, ayn = ay * kShrink, azn = az * kShrink;
-            const float bxn = bx * kShrink, byn = by * kShrink, bzn = bz * kShrink;
-            const float axf = ax * kGrow, ayf = ay * kGrow, azf = az * kGrow;
-            const float bxf = bx * kGrow, byf = by * kGrow, bzf = bz * kGrow;
-            const float limit = bestT * kGrow;
-            // near / far byte planes per axis, chosen by the direction sign
-            const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;
-            const uint32_t xlo0 = nx ? n3.z : n2.x, xlo1 = nx ? n3.w : n2.y;
-            const uint32_t xhi0 = nx ? n2.x : n3.z, xhi1 = nx ? n2.y : n3.w;
-            const uint32_t ylo0 = ny ? n4.x : n2.z, ylo1 = ny ? n4.y : n2.w;
-            const uint32_t yhi0 = ny ? n2.z : n4.x, yhi1 = ny ? n2.w : n4.y;
-            const uint32_t zlo0 = nz ? n4.z : n3.x, zlo1 = nz ? n4.w : n3.y;
-            const uint32_t zhi0 = nz ? n3.x : n4.z, zhi1 = nz ? n3.y : n4.w;
-            float tnear[kWide];
-            uint32_t hitMask = 0;
+    // One wide node: intersect the eight child boxes, continue with the nearest
+    // and leave the others on the stack.
+    __device__ __forceinline__ void nodeStep() {
+        RT_SITE(0);
+        RT_GUARD(node < (inBottom ? nodeLimit : topNodeLimit));
+        if (COUNT)
+            ++counters.nodes;
+        GlobalUint4 np = globalView(nodes + node);
+        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        const uint32_t imask = n0.w >> 24;
+        // child plane distance = q * a + b per axis; the near planes are shrunk
+        // and the far planes grown by 2^-20 relative, so rounding never rejects
+        // a box whose triangle the intersection test accepts
+        const float ax = __uint_as_float((n0.w & 0xffU) << 23) * idx;
+        const float ay = __uint_as_float(((n0.w >> 8) & 0xffU) << 23) * idy;
+        const float az = __uint_as_float(((n0.w >> 16) & 0xffU) << 23) * idz;
+        const float bx = (__uint_as_float(n0.x) - cur.ox) * idx;
+        const float by = (__uint_as_float(n0.y) - cur.oy) * idy;
+        const float bz = (__uint_as_float(n0.z) - cur.oz) * idz;
+        const float axn = ax * kShrink, ayn = ay * kShrink, azn = az * kShrink;
+        const float bxn = bx * kShrink, byn = by * kShrink, bzn = bz * kShrink;
+        const float axf = ax * kGrow, ayf = ay * kGrow, azf = az * kGrow;
+        const float bxf = bx * kGrow, byf = by * kGrow, bzf = bz * kGrow;
+        const float limit = bestT * kGrow;
+        // near / far byte planes per axis, chosen by the direction sign
+        const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;
+        const uint32_t xlo0 = nx ? n3.z : n2.x, xlo1 = nx ? n3.w : n2.y;
+        const uint32_t xhi0 = nx ? n2.x : n3.z, xhi1 = nx ? n2.y : n3.w;
+        const uint32_t ylo0 = ny ? n4.x : n2.z, ylo1 = ny ? n4.y : n2.w;
+        const uint32_t yhi0 = ny ? n2.z : n4.x, yhi1 = ny ? n2.w : n4.y;
+        const uint32_t zlo0 = nz ? n4.z : n3.x, zlo1 = nz ? n4.w : n3.y;
+        const uint32_t zhi0 = nz ? n3.x : n4.z, zhi1 = nz ? n3.y : n4.w;
+        float tnear[kWide];
+        uint32_t hitMask = 0;
 #pragma unroll
-            for (int i = 0; i < kWide; ++i) {
-                const int sh = 8 * (i & 3);
-                const float qxn = static_cast<float>(((i < 4 ? xlo0 : xlo1) >> sh) & 0xffU);
-                const float qxf = static_cast<float>(((i < 4 ? xhi0 : xhi1) >> sh) & 0xffU);
-                const float qyn = static_cast<float>(((i < 4 ? ylo0 : ylo1) >> sh) & 0xffU);
-                const float qyf = static_cast<float>(((i < 4 ? yhi0 : yhi1) >> sh) & 0xffU);
-                const float qzn = static_cast<float>(((i < 4 ? zlo0 : zlo1) >> sh) & 0xffU);
-                const float qzf = static_cast<float>(((i < 4 ? zhi0 : zhi1) >> sh) & 0xffU);
-                // fmaxf / fminf drop a NaN operand (0 * inf on an axis the ray
-                // is parallel to), which leaves that axis unconstrained
-                const float tn = fmaxf(fmaxf(fmaf(qxn, axn, bxn), fmaf(qyn, ayn, byn)), fmaxf(fmaf(qzn, azn, bzn), tminShrunk));
-                const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
-                const uint32_t meta = ((i < 4 ? n1.z : n1.w) >> sh) & 0xffU;
-                const bool present = ((imask >> i) & 1U) || (meta >> 5) != 0U;
-                tnear[i] = tn;
-                hitMask |= (present && tn <= tf) ? (1U << i) : 0U;
-            }
-            auto refOf = [&](int i) -> uint32_t {
-                const uint32_t meta = byteOf(n1.z, n1.w, i);
-                if ((imask >> i) & 1U)
-                    return n1.x + meta;
-                return kLeafBit | (meta >> 5) << 28 | (n1.y + (meta & 31U));
-            };
-            if (hitMask == 0U) {
-                node = pop();
-            } else {
+        for (int i = 0; i < kWide; ++i) {
+            const int sh = 8 * (i & 3);
+            const float qxn = static_cast<float>(((i < 4 ? xlo0 : xlo1) >> sh) & 0xffU);
+            const float qxf = static_cast<float>(((i < 4 ? xhi0 : xhi1) >> sh) & 0xffU);
+            const float qyn = static_cast<float>(((i < 4 ? ylo0 : ylo1) >> sh) & 0xffU);
+            const float qyf = static_cast<float>(((i < 4 ? yhi0 : yhi1) >> sh) & 0xffU);
+            const float qzn = static_cast<float>(((i < 4 ? zlo0 : zlo1) >> sh) & 0xffU);
+            const float qzf = static_cast<float>(((i < 4 ? zhi0 : zhi1) >> sh) & 0xffU);
+            // fmaxf / fminf drop a NaN operand (0 * inf on an axis the ray
+            // is parallel to), which leaves that axis unconstrained
+            const float tn = fmaxf(fmaxf(fmaf(qxn, axn, bxn), fmaf(qyn, ayn, byn)), fmaxf(fmaf(qzn, azn, bzn), tminShrunk));
+            const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
+            const uint32_t meta = ((i < 4 ? n1.z : n1.w) >> sh) & 0xffU;
+            const bool present = ((imask >> i) & 1U) || (meta >> 5) != 0U;
+            tnear[i] = tn;
+            hitMask |= (present && tn <= tf) ? (1U << i) : 0U;
+        }
+        auto refOf = [&](int i) -> uint32_t {
+            const uint32_t meta = byteOf(n1.z, n1.w, i);
+            if ((imask >> i) & 1U)
+                return n1.x + meta;
+            return kLeafBit | (meta >> 5) << 28 | (n1.y + (meta & 31U));
+        };
+        if (hitMask == 0U) {
+            node = pop();
+            return;
+        }
 #if RT_TRACE_SORTED_PUSH
-                // push all but the nearest, farthest first
-                while (hitMask & (hitMask - 1U)) {
-                    float far = -INFINITY;
-                    int which = 0;
+        // push all but the nearest, farthest first
+        while (hitMask & (hitMask - 1U)) {
+            RT_SITE(1);
+            float far = -INFINITY;
+            int which = 0;
 #pragma unroll
-                    for (int i = 0; i < kWide; ++i)
-                        if (((hitMask >> i) & 1U) && tnear[i] >= far) {
-                            far = tnear[i];
-                            which = i;
-                        }
-                    push(refOf(which), far);
-                    hitMask &= ~(1U << which);
+            for (int i = 0; i < kWide; ++i)
+                if (((hitMask >> i) & 1U) && tnear[i] >= far) {
+                    far = tnear[i];
+                    which = i;
                 }
-                node = refOf(__ffs(static_cast<int>(hitMask)) - 1);
+            push(refOf(which), far);
+            hitMask &= ~(1U << which);
+        }
+        node = refOf(__ffs(static_cast<int>(hitMask)) - 1);
 #else
-                // enter the nearest, push the others in slot order
-                float nearest = INFINITY;
-                int which = 0;
+        // enter the nearest, push the others in slot order
+        float nearest = INFINITY;
+        int which = 0;
 #pragma unroll
-                for (int i = 0; i < kWide; ++i)
-                    if (((hitMask >> i) & 1U) && tnear[i] < nearest) {
-                        nearest = tnear[i];
-                        which = i;
-                    }
-                hitMask &= ~(1U << which);
-                while (hitMask) {
-                    const int i = __ffs(static_cast<int>(hitMask)) - 1;
-                    hitMask &= hitMask - 1U;
-                    float t = tnear[0];
-#pragma unroll
-                    for (int k = 1; k < kWide; ++k)
-                        t = i == k ? tnear[k] : t;
-                    push(refOf(i), t);
-                }
-                node = refOf(which);
-#endif
+        for (int i = 0; i < kWide; ++i)
+            if (((hitMask >> i) & 1U) && tnear[i] < nearest) {
+                nearest = tnear[i];
+                which = i;
             }
+        hitMask &= ~(1U << which);
+        while (hitMask) {
+            const int i = __ffs(static_cast<int>(hitMask)) - 1;
+            hitMask &= hitMask - 1U;
+            float t = tnear[0];
+#pragma unroll
+            for (int k = 1; k < kWide; ++k)
+                t = i == k ? tnear[k] : t;
+            push(refOf(i), t);
         }
-        if (node == kDone)
-            break;
-        if (!inBottom) {
-            // ---- top-level leaf: enter the instance ----
-            if (COUNT)
-                ++counters.instances;
-            const InstanceRecord* record = instances + (node & 0x0fffffffU);
-            GlobalUint4 m = globalView(record);
-            const uint4 q0 = m[0], q1 = m[1], q2 = m[2], q3 = m[3], q4 = m[4];
-            const float4 r0 = make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w));
-            const float4 r1 = make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w));
-            const float4 r2 = make_float4(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
-            push(kSentinel, 0.0f);
-            cur.ox = ((r0.x * world.ox + r0.y * world.oy) + r0.z * world.oz) + r0.w;
-            cur.oy = ((r1.x * world.ox + r1.y * world.oy) + r1.z * world.oz) + r1.w;
-            cur.oz = ((r2.x * world.ox + r2.y * world.oy) + r2.z * world.oz) + r2.w;
-            cur.dx = (r0.x * world.dx + r0.y * world.dy) + r0.z * world.dz;
-            cur.dy = (r1.x * world.dx + r1.y * world.dy) + r1.z * world.dz;
-            cur.dz = (r2.x * world.dx + r2.y * world.dy) + r2.z * world.dz;
-            shear = makeShear(cur);
-            idx = __builtin_amdgcn_rcpf(cur.dx);
-            idy = __builtin_amdgcn_rcpf(cur.dy);
-            idz = __builtin_amdgcn_rcpf(cur.dz);
-            nodes = reinterpret_cast<const WideNode*>(static_cast<uintptr_t>(q3.x) | static_cast<uintptr_t>(q3.y) << 32);
-            triangles = reinterpret_cast<const PackedTriangle*>(static_cast<uintptr_t>(q3.z) |
-                                                                static_cast<uintptr_t>(q3.w) << 32);
-            instanceId = q4.x;
-            inBottom = true;
-            node = 0;
-            continue;
-        }
-        // ---- bottom-level leaf: triangles ----
+        node = refOf(which);
+#endif
+    }
+
+    // Top-level leaf: move the ray into the instance's object space.
+    __device__ __forceinline__ void enterInstance() {
+        RT_SITE(4);
+        RT_GUARD((node & 0x0fffffffU) < instanceLimit);
+        if (COUNT)
+            ++counters.instances;
+        const InstanceRecord* record = instances + (node & 0x0fffffffU);
+        GlobalUint4 m = globalView(record);
+        const uint4 q0 = m[0], q1 = m[1], q2 = m[2], q3 = m[3], q4 = m[4];
+        const float4 r0 = make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w));
+        const float4 r1 = make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w));
+        const float4 r2 = make_float4(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
+        push(kSentinel, 0.0f);
+        cur.ox = ((r0.x * world.ox + r0.y * world.oy) + r0.z * world.oz) + r0.w;
+        cur.oy = ((r1.x * world.ox + r1.y * world.oy) + r1.z * world.oz) + r1.w;
+        cur.oz = ((r2.x * world.ox + r2.y * world.oy) + r2.z * world.oz) + r2.w;
+        cur.dx = (r0.x * world.dx + r0.y * world.dy) + r0.z * world.dz;
+        cur.dy = (r1.x * world.dx + r1.y * world.dy) + r1.z * world.dz;
+        cur.dz = (r2.x * world.dx + r2.y * world.dy) + r2.z * world.dz;
+        shear = makeShear(cur);
+        idx = __builtin_amdgcn_rcpf(cur.dx);
+        idy = __builtin_amdgcn_rcpf(cur.dy);
+        idz = __builtin_amdgcn_rcpf(cur.dz);
+        nodes = reinterpret_cast<const WideNode*>(static_cast<uintptr_t>(q3.x) | static_cast<uintptr_t>(q3.y) << 32);
+        triangles = reinterpret_cast<const PackedTriangle*>(static_cast<uintptr_t>(q3.z) | static_cast<uintptr_t>(q3.w) << 32);
+        instanceId = q4.x;
+        nodeLimit = q4.z;
+        triangleLimit = q4.w;
+        inBottom = true;
+        node = 0;
+    }
+
+    // Bottom-level leaf: tests its next triangle.  The leaf reference counts down;
+    // after the last triangle the lane moves on to the next stack entry.
+    __device__ __forceinline__ void triangleStep() {
+        RT_SITE(3);
+        if (COUNT)
+            ++counters.triangles;
         const uint32_t count = (node >> 28) & 7U;
         const uint32_t first = node & 0x0fffffffU;
-        for (uint32_t k = 0; k < count; ++k) {
-            if (COUNT)
-                ++counters.triangles;
-            GlobalUint4 tp = globalView(triangles + first + k);
-            const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-            float t, u, v;
-            if (intersectTriangle(cur, shear, p0, p1, p2, tmin, bestT, t, u, v)) {
-                const uint32_t prim = p0.w;
-                // intersectTriangle only returns t <= bestT
-                if (t < bestT || instanceId < bestInst || (instanceId == bestInst && prim < bestPrim)) {
-                    bestT = t;
-                    bestU = u;
-                    bestV = v;
-                    bestPrim = prim;
-                    bestInst = instanceId;
-                    found = true;
-                }
+        RT_GUARD(first < triangleLimit);
+        GlobalUint4 tp = globalView(triangles + first);
+        const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+        float t, u, v;
+        if (intersectTriangle(cur, shear, p0, p1, p2, tmin, bestT, t, u, v)) {
+            const uint32_t prim = p0.w;
+            // intersectTriangle only returns t <= bestT
+            if (t < bestT || instanceId < bestInst || (instanceId == bestInst && prim < bestPrim)) {
+                bestT = t;
+                bestU = u;
+                bestV = v;
+                bestPrim = prim;
+                bestInst = instanceId;
+                found = true;
             }
         }
         if (anyHit && found)
-            break;
-        node = pop();
+            node = kDone;
+        else if (count > 1U)
+            node = kLeafBit | (count - 1U) << 28 | (first + 1U);
+        else
+            node = pop();
     }
-    if (!found)
-        return {tmax, 0.0f, 0.0f, kNoHit, kNoHit};
-    return {bestT, bestU, bestV, bestPrim, bestInst};
+};
+
+// Hands out ray indices [0, n) to the waves of a persistent launch.  The range
+// is cut into eight contiguous chunks, one per XCD (workgroups are dealt to the
+// XCDs round-robin, so blockIdx & 7 names the XCD): a wave drains the chunk of
+// its own XCD first, which keeps neighbouring rays behind one L2, and then
+// helps with the others.  `cursors` holds one counter per chunk, kFeedStride
+// words apart, zeroed before the launch.
+struct RayFeed {
+    uint32_t* cursors;
+    uint32_t n, chunkSize;
+    uint32_t chunk;      // chunk this wave draws from (wave-uniform)
+    uint32_t exhausted;  // chunks found empty so far (wave-uniform)
+
+    __device__ __forceinline__ RayFeed(uint32_t* c, uint32_t count) : cursors(c), n(count) {
+        chunkSize = ((count + 7U) / 8U + 63U) & ~63U;
+        chunk = blockIdx.x & 7U;
+        exhausted = 0;
+    }
+    __device__ __forceinline__ bool drained() const { return exhausted >= 8U; }
+
+    // Every lane of the wave calls this with the same `idleMask` (lanes that want
+    // a ray).  Returns true with `index` set for the lanes that got one.
+    __device__ __forceinline__ bool take(unsigned long long idleMask, bool idle, uint32_t& index) {
+        const int lane = threadIdx.x & 63;
+        while (exhausted < 8U) {
+            const uint32_t begin = min(chunk * chunkSize, n), end = min(begin + chunkSize, n);
+            const uint32_t want = __popcll(idleMask);
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&cursors[chunk * kFeedStride], want);
+            base = __shfl(base, 0, 64);
+            if (base < end - begin) {
+                const uint32_t mine = begin + base + __popcll(idleMask & ((1ULL << lane) - 1ULL));
+                index = mine;
+                return idle && mine < end;
+            }
+            ++exhausted;
+            chunk = (chunk + 1U) & 7U;
+        }
+        return false;
+    }
+};
+
+// Persistent traversal loop of one lane.  fetch(index, traversal) loads ray
+// `index` and calls traversal.begin(...), returning false when the ray needs no
+// walk; store(index, result) consumes a finished ray.
+//
+// Per turn every lane with a ray runs a burst: up to RT_TRACE_NODE_STEPS wide
+// nodes, then at most one leaf, so the lanes of a wave run the node code
+// together and the leaf code together.
+template <bool COUNT, typename Fetch, typename Store>
+__device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Fetch&& fetch, Store&& store) {
+    bool active = false;
+    uint32_t rayIndex = 0;
+    for (;;) {
+        const unsigned long long idleMask = __ballot(!active);
+        if (!feed.drained() && __popcll(idleMask) >= RT_TRACE_REFILL) {
+            uint32_t index = 0;
+            if (feed.take(idleMask, !active, index)) {
+                if (fetch(index, walk)) {
+                    active = true;
+                    rayIndex = index;
+                }
+            }
+        }
+        if (__ballot(active) == 0ULL) {
+            if (feed.drained())
+                break;
+            continue;
+        }
+        if (active) {
+#ifdef RT_TRACE_PROFILE
+            float* profile = walk.profile;
+            uint32_t raySteps = 0;
+            RT_SITE(5);
+#endif
+            // a burst: a few wide nodes, then at most one leaf
+#pragma unroll 1
+            for (int s = 0; s < RT_TRACE_NODE_STEPS && !(walk.node & kLeafBit); ++s)
+                walk.nodeStep();
+            if ((walk.node & kLeafBit) && walk.node != kDone) {
+                if (!walk.inBottom) {
+                    walk.enterInstance();
+                } else {
+                    const uint32_t count = (walk.node >> 28) & 7U;
+                    for (uint32_t k = 0; k < count && walk.node != kDone; ++k)
+                        walk.triangleStep();
+                }
+            }
+        }
+        if (active && walk.node == kDone) {
+            store(rayIndex, walk.result());
+            active = false;
+#ifdef RT_TRACE_PROFILE
+            walk.finishRay();
+#endif
+        }
+    }
+#ifdef RT_TRACE_PROFILE
+    walk.flushProfile();
+#endif
+}
+
+// Workgroups of a persistent traversal launch that fill `device` once: one per
+// CU and wave slot the kernels' launch bounds leave room for.
+inline uint32_t persistentBlocks(int device) {
+    static std::atomic<uint32_t> cached[64];
+    const int slot = device >= 0 && device < 64 ? device : 0;
+    uint32_t blocks = cached[slot].load(std::memory_order_relaxed);
+    if (blocks == 0U) {
+        int units = 0;
+        if (hipDeviceGetAttribute(&units, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || units <= 0)
+            units = 256;
+        blocks = static_cast<uint32_t>(units) * RT_TRACE_MIN_WAVES * 4U / (kTraceBlock / 64) * RT_TRACE_GRID_SCALE;
+        cached[slot].store(blocks, std::memory_order_relaxed);
+    }
+    return blocks;
 }
 
 }  // namespace rt

@@ -49,6 +49,7 @@ struct Buffers {
     float4* lastOrigin;          // xyz + flags
     float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
     uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length
+    uint32_t* feed;              // ray-feed cursors of the trace launch (kFeedWords), zero between launches
     unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
                                  // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
     rt_photon* photonTemp;       // photon pass: one slot per emission of the batch
@@ -118,29 +119,115 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
         b.sample[k][i] = zero;
 }
 
-// Closest hit for the first counts[which] rays of a queue (the extend stage).
+// The ray stage of a bounce, one persistent launch for both kinds of ray:
+//   * extend: closest hit for the counts[which] rays of queue `which` (skipped
+//     when which < 0);
+//   * shadow: visible(), device.cu:548-559, for the counts[2] rays queued by the
+//     previous shade launch (skipped when withShadow is 0): the light is seen
+//     when nothing is hit before it (delta lights, environment) or when the
+//     closest hit is the sampled emissive triangle itself; then the deferred
+//     contribution is added.
+// The two kinds are independent, and tracing them together leaves one tail of
+// slow rays per bounce instead of two.
+//
+// "The closest hit is that triangle" is decided without a closest-hit walk: the
+// shadow ray is intersected with the sampled triangle first (same arithmetic as
+// the traversal, so the same t), and the scene is then searched for ANY hit that
+// beats (t, instance, primitive) of that candidate - the first one found ends
+// the walk.  The outcome is the same bit for bit.
+//
 // COUNT adds the visited nodes / tested triangles / entered instances to stats[4..6].
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void extendKernel(const WideNode* topNodes, const InstanceRecord* instances,
-                                                            Buffers b, int which) {
+__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(const WideNode* topNodes, const InstanceRecord* instances,
+                                                           const ShadeInstance* shadeInstances,
+                                                           const rt_hit_group_data* geometries, Buffers b, int which,
+                                                           int withShadow, uint4 limits) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
-    const uint32_t n = b.counts[which];
-    const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
-    if (blockIdx.x >= blocks)
-        return;
-    const uint32_t ray = xcdRemap(blockIdx.x, blocks) * kTraceBlock + threadIdx.x;
-    TraceCounters local;
-    if (ray < n) {
-        const float4 o4 = b.rayOrigin[which][ray];
-        const float4 d4 = b.rayDirection[which][ray];
-        const TraceResult r =
-            traceRay<COUNT>(topNodes, instances, Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit,
-                            false, ldsView(&stackRef[0][threadIdx.x]), ldsView(&stackT[0][threadIdx.x]), kTraceBlock, local);
-        b.hits[ray] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
-        b.hitInstance[ray] = r.instance;
+    uint32_t spillRef[kPrivateStack];
+    float spillT[kPrivateStack];
+    Traversal<COUNT> walk(topNodes, limits.x, instances, limits.y, ldsView(&stackRef[0][threadIdx.x]),
+                          ldsView(&stackT[0][threadIdx.x]), kTraceBlock, spillRef, spillT);
+    const uint32_t extendCount = which >= 0 ? b.counts[which] : 0U;
+    const uint32_t shadowCount = withShadow ? b.counts[2] : 0U;
+    RayFeed feed(b.feed, extendCount + shadowCount);  // extend rays first: they are the longer ones
+#ifdef RT_TRACE_PROFILE
+    walk.profileBase = 16;
+#endif
+    const float4* origins = b.rayOrigin[which >= 0 ? which : 0];
+    const float4* directions = b.rayDirection[which >= 0 ? which : 0];
+    tracePersistent<COUNT>(
+        walk, feed,
+        [&](uint32_t index, Traversal<COUNT>& w) {
+            if (index < extendCount) {
+                const float4 o4 = origins[index];
+                const float4 d4 = directions[index];
+                w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit, false);
+                return true;
+            }
+            const uint32_t ray = index - extendCount;
+            const float4 o4 = b.shadowOrigin[ray];
+            const float4 d4 = b.shadowDirection[ray];
+            const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
+            float limit = d4.w;
+            uint32_t candidateInstance = kNoHit, candidatePrimitive = kNoHit;
+            if (__float_as_uint(b.shadowContribution[ray].w) & 4U) {
+                // the light's own triangle: where the ray meets it bounds the search
+                const uint2 target = b.shadowTarget[ray];
+                if (target.x >= limits.z || shadeInstances[target.x].geometry >= limits.w) {
+                    ++w.violations;
+                    return false;
+                }
+                const ShadeInstance& record = shadeInstances[target.x];
+                const rt_hit_group_data geometry = geometries[record.geometry];
+                const rt_uint3 triangle = geometry.indices[target.y];
+                const rt_float3 a = geometry.vertices[triangle.x].position;
+                const rt_float3 bb = geometry.vertices[triangle.y].position;
+                const rt_float3 c = geometry.vertices[triangle.z].position;
+                const float* m = record.toObject;
+                Ray local;
+                local.ox = ((m[0] * world.ox + m[1] * world.oy) + m[2] * world.oz) + m[3];
+                local.oy = ((m[4] * world.ox + m[5] * world.oy) + m[6] * world.oz) + m[7];
+                local.oz = ((m[8] * world.ox + m[9] * world.oy) + m[10] * world.oz) + m[11];
+                local.dx = (m[0] * world.dx + m[1] * world.dy) + m[2] * world.dz;
+                local.dy = (m[4] * world.dx + m[5] * world.dy) + m[6] * world.dz;
+                local.dz = (m[8] * world.dx + m[9] * world.dy) + m[10] * world.dz;
+                const Shear shear = makeShear(local);
+                float t, u, v;
+                if (!intersectTriangle(local, shear,
+                                       make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), 0U),
+                                       make_uint4(__float_as_uint(bb.x), __float_as_uint(bb.y), __float_as_uint(bb.z), 0U),
+                                       make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0U),
+                                       o4.w, limit, t, u, v))
+                    return false;  // the ray does not reach the sampled triangle at all
+                limit = t;
+                candidateInstance = target.x;
+                candidatePrimitive = target.y;
+            }
+            w.begin(world, o4.w, limit, candidateInstance, candidatePrimitive, true);
+            return true;
+        },
+        [&](uint32_t index, const TraceResult& r) {
+            if (index < extendCount) {
+                b.hits[index] = make_uint4(__float_as_uint(r.t), __float_as_uint(r.u), __float_as_uint(r.v), r.primitive);
+                b.hitInstance[index] = r.instance;
+                return;
+            }
+            if (r.primitive != kNoHit)
+                return;  // something lies in front of the light (or of the sampled triangle)
+            const uint32_t ray = index - extendCount;
+            const float4 c4 = b.shadowContribution[ray];
+            const uint32_t path = b.shadowPath[ray];
+            const uint32_t lobe = __float_as_uint(c4.w) & 3U;
+            const float4 acc = b.sample[lobe][path];
+            b.sample[lobe][path] = make_float4(acc.x + c4.x, acc.y + c4.y, acc.z + c4.z, 0.0f);
+        });
+    if (__ballot(walk.violations != 0U)) {
+        if (walk.violations)
+            atomicAdd(&b.stats[7], static_cast<unsigned long long>(walk.violations));
     }
     if (COUNT) {
+        TraceCounters local = walk.counters;
 #pragma unroll
         for (int delta = 32; delta >= 1; delta >>= 1) {
             local.nodes += __shfl_down(local.nodes, delta, 64);
@@ -353,82 +440,12 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     }
 }
 
-// visible(), device.cu:548-559: the light is seen when nothing is hit before
-// it (delta lights, environment) or when the closest hit is the sampled
-// emissive triangle itself; then the deferred contribution is added.
-//
-// "The closest hit is that triangle" is decided without a closest-hit walk: the
-// ray is intersected with the sampled triangle first (same arithmetic as the
-// traversal, so the same t), and the scene is then searched for ANY hit that
-// beats (t, instance, primitive) of that candidate - the first one found ends
-// the walk.  The outcome is the same bit for bit.
-__global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void shadowKernel(const WideNode* topNodes, const InstanceRecord* instances,
-                                                            const ShadeInstance* shadeInstances,
-                                                            const rt_hit_group_data* geometries, Buffers b) {
-    __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
-    __shared__ float stackT[kLdsStack][kTraceBlock];
-    const uint32_t n = b.counts[2];
-    const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
-    if (blockIdx.x >= blocks)
-        return;
-    const uint32_t ray = xcdRemap(blockIdx.x, blocks) * kTraceBlock + threadIdx.x;
-    if (ray >= n)
-        return;
-    const float4 o4 = b.shadowOrigin[ray];
-    const float4 d4 = b.shadowDirection[ray];
-    const float4 c4 = b.shadowContribution[ray];
-    const uint32_t bits = __float_as_uint(c4.w);
-    const bool needsTriangle = bits & 4U;
-    const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
-    float limit = d4.w;
-    uint32_t candidateInstance = kNoHit, candidatePrimitive = kNoHit;
-    bool possible = true;
-    if (needsTriangle) {
-        const uint2 target = b.shadowTarget[ray];
-        const ShadeInstance& record = shadeInstances[target.x];
-        const rt_hit_group_data geometry = geometries[record.geometry];
-        const rt_uint3 triangle = geometry.indices[target.y];
-        const rt_float3 a = geometry.vertices[triangle.x].position;
-        const rt_float3 bb = geometry.vertices[triangle.y].position;
-        const rt_float3 c = geometry.vertices[triangle.z].position;
-        const float* m = record.toObject;
-        Ray local;
-        local.ox = ((m[0] * world.ox + m[1] * world.oy) + m[2] * world.oz) + m[3];
-        local.oy = ((m[4] * world.ox + m[5] * world.oy) + m[6] * world.oz) + m[7];
-        local.oz = ((m[8] * world.ox + m[9] * world.oy) + m[10] * world.oz) + m[11];
-        local.dx = (m[0] * world.dx + m[1] * world.dy) + m[2] * world.dz;
-        local.dy = (m[4] * world.dx + m[5] * world.dy) + m[6] * world.dz;
-        local.dz = (m[8] * world.dx + m[9] * world.dy) + m[10] * world.dz;
-        const Shear shear = makeShear(local);
-        float t, u, v;
-        possible = intersectTriangle(local, shear,
-                                     make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), 0U),
-                                     make_uint4(__float_as_uint(bb.x), __float_as_uint(bb.y), __float_as_uint(bb.z), 0U),
-                                     make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0U),
-                                     o4.w, limit, t, u, v);
-        limit = t;
-        candidateInstance = target.x;
-        candidatePrimitive = target.y;
-    }
-    bool seen = false;
-    if (possible) {
-        TraceCounters unused;
-        const TraceResult r = traceRay<false>(topNodes, instances, world, o4.w, limit, candidateInstance,
-                                              candidatePrimitive, true, ldsView(&stackRef[0][threadIdx.x]),
-                                              ldsView(&stackT[0][threadIdx.x]), kTraceBlock, unused);
-        seen = r.primitive == kNoHit;  // nothing in front of the light (or of the sampled triangle)
-    }
-    if (seen) {
-        const uint32_t path = b.shadowPath[ray];
-        const uint32_t lobe = bits & 3U;
-        const float4 acc = b.sample[lobe][path];
-        b.sample[lobe][path] = make_float4(acc.x + c4.x, acc.y + c4.y, acc.z + c4.z, 0.0f);
-    }
-}
-
-// Bookkeeping between bounces: ray statistics, then the consumed queues are emptied.
+// Bookkeeping between bounces: ray statistics, then the consumed queues are emptied
+// and the ray-feed cursors rewound.
 __global__ void advanceKernel(Buffers b, int which) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < kFeedWords; k += blockDim.x)
+        b.feed[k] = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && which >= 0) {
         b.stats[0] += b.counts[which];
         b.stats[1] += b.counts[2];
         b.counts[which] = 0;
@@ -727,6 +744,7 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     for (int k = 0; k < 6; ++k)
         allocate(b.sample[k], maxPaths);
     allocate(b.counts, 4);
+    allocate(b.feed, kFeedWords);
     allocate(b.stats, 8);
     allocate(b.photonTemp, maxPaths);
     allocate(b.photonFlags, static_cast<size_t>(maxPaths) + 1);
@@ -820,6 +838,12 @@ struct StageTimer {
 
 }  // namespace
 
+// Array sizes the ray stage checks references against: top-level nodes, instances, shading records, geometries.
+static uint4 limitsOf(const rt_scene* scene) {
+    return make_uint4(static_cast<uint32_t>(scene->nodeCount), scene->instanceCount, scene->shadeInstanceCount,
+                      scene->hitGroupCount);
+}
+
 static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
     if (!w || !params)
         return failInvalid("null pointer");
@@ -836,6 +860,28 @@ static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* para
         return failInvalid("launch parameters carry no materials");
     return RT_SUCCESS;
 }
+
+#ifdef RT_TRACE_PROFILE
+// Development aid: copies out (and optionally clears) the per-site issue / lane sums of the wavefront kernels.
+rt_status rt_trace_profile(float* out64, int reset) {
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(gTraceProfile), sizeof(float) * 64));
+    if (reset) {
+        const float zero[64] = {};
+        RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gTraceProfile), zero, sizeof(zero)));
+    }
+    return RT_SUCCESS;
+}
+rt_status rt_trace_histogram(uint32_t* out64, int reset) {
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(gTraceHistogram), sizeof(uint32_t) * 64));
+    if (reset) {
+        const uint32_t zero[64] = {};
+        RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gTraceHistogram), zero, sizeof(zero)));
+    }
+    return RT_SUCCESS;
+}
+#endif
 
 rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin, uint32_t pixelEnd,
                            void* stream) {
@@ -858,34 +904,41 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     auto s = static_cast<hipStream_t>(stream);
     const Buffers& b = w->buffers;
     const unsigned blocks = divUp(count, kShadeBlock);
+    const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
     const bool counted = w->flags & RT_WAVEFRONT_COUNT_TRAVERSAL;
+    RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
     {
         StageTimer timer(w, s, 0);
         hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count,
                            seedSample, b);
     }
+    const uint4 limits = limitsOf(scene);
+    // stage 1 is the ray stage (traceKernel), stage 3 the bookkeeping between bounces
+    auto trace = [&](int which, int withShadow) {
+        StageTimer timer(w, s, 1);
+        if (counted)
+            hipLaunchKernelGGL(traceKernel<true>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
+                               scene->shadeInstances, scene->hitGroups, b, which, withShadow, limits);
+        else
+            hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
+                               scene->shadeInstances, scene->hitGroups, b, which, withShadow, limits);
+    };
+    if (params->maxDepth > 0) {
+        trace(0, 0);
+        StageTimer timer(w, s, 3);
+        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, -1);
+    }
     for (uint32_t depth = 0; depth < params->maxDepth; ++depth) {
         const int which = depth & 1U;
-        {
-            StageTimer timer(w, s, 1);
-            if (counted)
-                hipLaunchKernelGGL(extendKernel<true>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                                   scene->instances, b, which);
-            else
-                hipLaunchKernelGGL(extendKernel<false>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                                   scene->instances, b, which);
-        }
         {
             StageTimer timer(w, s, 2);
             hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
         }
-        {
-            StageTimer timer(w, s, 3);
-            hipLaunchKernelGGL(shadowKernel, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
-                               scene->shadeInstances, scene->hitGroups, b);
-        }
-        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
+        // the shadow rays of this bounce travel with the extend rays of the next
+        trace(depth + 1 < params->maxDepth ? 1 - which : -1, 1);
+        StageTimer timer(w, s, 3);
+        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);
     }
     {
         StageTimer timer(w, s, 4);
@@ -907,16 +960,19 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
     while (done < emissionCount) {
         const uint32_t count = std::min(b.capacity, emissionCount - done);
         const unsigned blocks = divUp(count, kShadeBlock);
+        const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
+        const uint4 limits = limitsOf(scene);
         RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 4, s));
+        RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
         hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, firstEmission + done,
                            count, b);
         for (uint32_t depth = 0; depth < 10U; ++depth) {
             const int which = depth & 1U;
-            hipLaunchKernelGGL(extendKernel<false>, dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                               scene->instances, b, which);
+            hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                               scene->instances, scene->shadeInstances, scene->hitGroups, b, which, 0, limits);
             hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
-            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, b, which);
+            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);
         }
         // emission-ordered append: offsets = exclusive scan of the flags (with a
         // trailing zero so that offsets[count] is the batch total)

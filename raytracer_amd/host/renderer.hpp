@@ -70,7 +70,7 @@ public:
     // Measurement switches: event-time every stage launch / count traversal steps.
     void setMeasurement(bool timeStages, bool countTraversal);
     // Event-timed milliseconds and launch counts per stage since the last call:
-    // generate, extend, shade, shadow, accumulate.  Waits for the GPU.
+    // generate, trace, shade, queue bookkeeping, accumulate.  Waits for the GPU.
     void stageTimings(float milliseconds[5], std::uint32_t launches[5]);
     void synchronize() const;
     const rt_launch_params& launchParams() const;

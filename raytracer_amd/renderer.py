@@ -292,7 +292,7 @@ class Renderer:
         out = (C.c_uint64 * 8)()
         _check(load().rth_renderer_statistics(self.handle, out))
         return dict(extend_rays=out[0], shadow_rays=out[1], gather_queries=out[2], gathered_photons=out[3],
-                    nodes=out[4], triangles=out[5], instances=out[6])
+                    nodes=out[4], triangles=out[5], instances=out[6], refused_references=out[7])
 
     def set_measurement(self, time_stages=False, count_traversal=False):
         _check(load().rth_renderer_set_measurement(self.handle, int(time_stages), int(count_traversal)))
@@ -302,7 +302,7 @@ class Renderer:
         ms = (C.c_float * 5)()
         n = (C.c_uint32 * 5)()
         _check(load().rth_renderer_stage_timings(self.handle, ms, n))
-        names = ("generate", "extend", "shade", "shadow", "accumulate")
+        names = ("generate", "trace", "shade", "advance", "accumulate")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def synchronize(self):
