@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--workload", default="dragon-cornell",
                    choices=["dragon-cornell", "cornell", "sphere-field", "caustic-lab"])
     p.add_argument("--photons", type=int, default=1 << 23)
+    p.add_argument("--tiles", type=int, default=2,
+                   help="concurrent parts of the frame per render() call (1 = one stream)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-photon-bench", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -174,13 +176,12 @@ def main():
     tris_per_ray = c["triangles"] / counted_rays
     bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
+    renderer.set_concurrent_tiles(args.tiles)
     renderer.set_measurement(time_stages=False)
     for _ in range(args.warmup):
         renderer.render()
     renderer.synchronize()
     renderer.statistics()
-    renderer.set_measurement(time_stages=True)
-    renderer.stage_timings()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -193,8 +194,22 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stats = renderer.statistics()
-    stages = renderer.stage_timings()
     rays = float(stats["extend_rays"] + stats["shadow_rays"])
+
+    # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
+    # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
+    # bracketed by HIP events on the stream it runs on.
+    renderer.set_concurrent_tiles(1)
+    renderer.set_measurement(time_stages=True)
+    renderer.render()
+    renderer.stage_timings()
+    renderer.statistics()
+    for _ in range(args.steps):
+        renderer.render()
+    renderer.synchronize()
+    stages = renderer.stage_timings()
+    staged = renderer.statistics()
+    staged_rays = float(staged["extend_rays"] + staged["shadow_rays"])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,7 +230,7 @@ def main():
         return
 
     trace_ms, trace_launches = stages["trace"]
-    achieved = rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
+    achieved = staged_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
     p = renderer.launch_params()
     out = {
         "metric": "closest_hit_mrays_per_s",
@@ -243,7 +258,8 @@ def main():
             "parallelism": f"replicated scene, {world} x sample-index shards, no data-path collective",
         },
         "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
-        "trace_kernel_mrays_per_s": rays / (trace_ms * 1e-3) / 1e6,
+        "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
+        "concurrent_tiles": args.tiles,
         "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {
             "bound": "hbm",

@@ -2,7 +2,8 @@
 //
 // Bottom level (replaces the OptiX GAS build, renderer.cpp:343-396), all on the
 // device: triangle bounds -> 63-bit Morton codes of the centroids -> stable radix
-// sort -> binary radix tree (Karras 2012) -> bottom-up bounds -> top-down
+// sort -> binary radix tree (Karras 2012) -> bottom-up bounds (or, on request,
+// a binary tree by locally-ordered clustering, section 3b) -> top-down
 // collapse into 8-wide nodes, one level per launch, where the child with the
 // largest surface area is opened first and subtrees of at most kMaxLeaf
 // triangles become leaf children -> 8-bit quantised child boxes.  Node and
@@ -214,6 +215,152 @@ __global__ __launch_bounds__(256) void refitKernel(const uint32_t* left, const u
     }
 }
 
+// ---- 3b. agglomerative binary tree (parallel locally-ordered clustering) ----
+//
+// Alternative to the radix tree, after Meister and Bittner (2018): the clusters
+// (first the triangles in Morton order) each look kPlocRadius places to either
+// side for the neighbour whose union with them has the smallest surface area;
+// pairs that chose each other merge into a new node, the array is compacted and
+// the search repeats until one cluster is left.  The trees come out close to a
+// surface-area-heuristic build.  Every choice is made with ties to the lower index and slots come from
+// prefix sums, so the tree is the same on every run.
+//
+// Node ids as above (internal 0 .. n-2, leaf k = (n-1) + k); internal ids are
+// handed out from the top down, so the last merge - the root - is id 0.
+
+constexpr int kPlocRadius = 16;
+
+__global__ __launch_bounds__(256) void plocNearestKernel(const uint32_t* clusters, uint32_t m, const Box4* bounds,
+                                                         uint32_t* nearest) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m)
+        return;
+    const Box4 mine = bounds[clusters[i]];
+    const uint32_t lo = i > static_cast<uint32_t>(kPlocRadius) ? i - kPlocRadius : 0U;
+    const uint32_t hi = min(m - 1U, i + kPlocRadius);
+    float best = INFINITY;
+    uint32_t which = i;
+    for (uint32_t j = lo; j <= hi; ++j) {
+        if (j == i)
+            continue;
+        const float area = halfArea(merge(mine, bounds[clusters[j]]));
+        if (area < best || which == i) {
+            best = area;
+            which = j;
+        }
+    }
+    nearest[i] = which;
+}
+
+// keep[i]: cluster i has a slot in the next array (it survives, or it is the
+// lower partner of a merging pair); merges[i]: it is the lower partner.  Both
+// arrays end with a zero so that the exclusive scans yield the totals.
+__global__ __launch_bounds__(256) void plocFlagKernel(const uint32_t* nearest, uint32_t m, uint32_t* keep,
+                                                      uint32_t* merges) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m)
+        return;
+    if (i == m) {
+        keep[i] = 0;
+        merges[i] = 0;
+        return;
+    }
+    const uint32_t j = nearest[i];
+    const bool mutual = j != i && nearest[j] == i;
+    keep[i] = (!mutual || i < j) ? 1U : 0U;
+    merges[i] = (mutual && i < j) ? 1U : 0U;
+}
+
+__device__ inline uint32_t leavesBelow(uint32_t id, uint32_t n, const uint32_t* counts) {
+    return id >= n - 1U ? 1U : counts[id];
+}
+
+__global__ __launch_bounds__(256) void plocMergeKernel(const uint32_t* clusters, const uint32_t* nearest,
+                                                       const uint32_t* keepOffsets, const uint32_t* mergeOffsets,
+                                                       uint32_t m, uint32_t n, uint32_t idBase, Box4* bounds,
+                                                       uint32_t* left, uint32_t* right, uint32_t* parent,
+                                                       uint32_t* counts, uint32_t* clustersOut) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m)
+        return;
+    const uint32_t j = nearest[i];
+    const bool mutual = j != i && nearest[j] == i;
+    if (mutual && i > j)
+        return;  // absorbed by its partner
+    uint32_t id = clusters[i];
+    if (mutual) {
+        const uint32_t a = id, b = clusters[j];
+        id = idBase + mergeOffsets[i];
+        left[id] = a;
+        right[id] = b;
+        parent[a] = id;
+        parent[b] = id;
+        bounds[id] = merge(bounds[a], bounds[b]);
+        counts[id] = leavesBelow(a, n, counts) + leavesBelow(b, n, counts);
+    }
+    clustersOut[keepOffsets[i]] = id;
+}
+
+// Position of the first leaf below `id` in a depth-first walk of the tree: the
+// leaves of the left subtrees it lies to the right of, summed on the way up.
+__device__ inline uint32_t firstLeafBelow(uint32_t id, uint32_t n, const uint32_t* left, const uint32_t* right,
+                                          const uint32_t* parent, const uint32_t* counts) {
+    uint32_t first = 0, cur = id;
+    for (uint32_t p = parent[cur]; p != kNoHit; p = parent[cur]) {
+        if (right[p] == cur)
+            first += leavesBelow(left[p], n, counts);
+        cur = p;
+    }
+    return first;
+}
+
+// Leaves are renumbered by their depth-first position, so that every subtree
+// covers a contiguous range of the new triangle order (which the collapse
+// relies on).  Pass 1: where each leaf goes.
+__global__ __launch_bounds__(256) void plocLeafOrderKernel(uint32_t n, const uint32_t* left, const uint32_t* right,
+                                                           const uint32_t* parent, const uint32_t* counts,
+                                                           const uint32_t* order, const Box4* bounds,
+                                                           uint32_t* leafPosition, uint32_t* orderOut, Box4* leafBoundsOut) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    const uint32_t position = firstLeafBelow((n - 1U) + k, n, left, right, parent, counts);
+    leafPosition[k] = position;
+    orderOut[position] = order[k];
+    leafBoundsOut[position] = bounds[(n - 1U) + k];
+}
+
+// Pass 2: leaf ranges of the internal nodes.
+__global__ __launch_bounds__(256) void plocRangeKernel(uint32_t n, const uint32_t* left, const uint32_t* right,
+                                                       const uint32_t* parent, const uint32_t* counts, uint32_t* first,
+                                                       uint32_t* last) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n - 1U)
+        return;
+    const uint32_t begin = firstLeafBelow(id, n, left, right, parent, counts);
+    first[id] = begin;
+    last[id] = begin + counts[id] - 1U;
+}
+
+// Pass 3, once every walk up has finished: child references in the new leaf numbering.
+__global__ __launch_bounds__(256) void plocChildKernel(uint32_t n, uint32_t* left, uint32_t* right,
+                                                       const uint32_t* leafPosition) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n - 1U)
+        return;
+    const uint32_t l = left[id], r = right[id];
+    if (l >= n - 1U)
+        left[id] = (n - 1U) + leafPosition[l - (n - 1U)];
+    if (r >= n - 1U)
+        right[id] = (n - 1U) + leafPosition[r - (n - 1U)];
+}
+
+__global__ __launch_bounds__(256) void iotaKernel(uint32_t* out, uint32_t n, uint32_t base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = base + i;
+}
+
 // ---- 4. collapse into wide nodes --------------------------------------------
 
 struct Child {
@@ -405,6 +552,16 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
 
 // ---- host side --------------------------------------------------------------
 
+// Which binary tree the wide nodes are collapsed from: the Morton radix tree
+// unless RT_BLAS_BUILDER=ploc asks for the clustering build.  (Measured on an
+// MI355X the two trace within a few percent of each other on a dense mesh and
+// the radix tree is ahead on triangle soups, so it is the default.)
+enum class Builder { Clustering, RadixTree };
+static Builder builderChoice() {
+    const char* v = std::getenv("RT_BLAS_BUILDER");
+    return v && std::strcmp(v, "ploc") == 0 ? Builder::Clustering : Builder::RadixTree;
+}
+
 struct DeviceBuffer {
     void* data = nullptr;
     ~DeviceBuffer() {
@@ -440,7 +597,8 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_TRY(idxA.allocate(sizeof(uint32_t) * n));
     RT_TRY(idxB.allocate(sizeof(uint32_t) * n));
     RT_TRY(table.allocate(sizeof(uint32_t) * sortTableEntries(n)));
-    const size_t scanEntries = std::max(scanScratchEntries(sortTableEntries(n)), scanScratchEntries(maxNodes + 1));
+    const size_t scanEntries = std::max({scanScratchEntries(sortTableEntries(n)), scanScratchEntries(maxNodes + 1),
+                                         scanScratchEntries(static_cast<size_t>(n) + 1)});
     RT_TRY(partials.allocate(sizeof(uint32_t) * scanEntries));
     RT_TRY(left.allocate(sizeof(uint32_t) * n));
     RT_TRY(right.allocate(sizeof(uint32_t) * n));
@@ -475,7 +633,62 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
 
     hipLaunchKernelGGL(leafBoundsKernel, dim3(blocks), dim3(256), 0, stream, boxes.as<Box4>(), order, n,
                        bounds.as<Box4>());
-    if (n >= 2) {
+    if (n >= 2 && builderChoice() == Builder::Clustering) {
+        DeviceBuffer clustersA, clustersB, nearest, keep, merges, leafPosition, leafBounds;
+        RT_TRY(clustersA.allocate(sizeof(uint32_t) * n));
+        RT_TRY(clustersB.allocate(sizeof(uint32_t) * n));
+        RT_TRY(nearest.allocate(sizeof(uint32_t) * n));
+        RT_TRY(keep.allocate(sizeof(uint32_t) * (static_cast<size_t>(n) + 1)));
+        RT_TRY(merges.allocate(sizeof(uint32_t) * (static_cast<size_t>(n) + 1)));
+        RT_TRY(leafPosition.allocate(sizeof(uint32_t) * n));
+        RT_TRY(leafBounds.allocate(sizeof(Box4) * n));
+        uint32_t* counts = arrivals.as<uint32_t>();
+        uint32_t* current = clustersA.as<uint32_t>();
+        uint32_t* next = clustersB.as<uint32_t>();
+        hipLaunchKernelGGL(iotaKernel, dim3(blocks), dim3(256), 0, stream, current, n, n - 1U);
+        uint32_t m = n, created = 0;
+        while (m > 1) {
+            const unsigned grid = divUp(m + 1, 256);
+            hipLaunchKernelGGL(plocNearestKernel, dim3(grid), dim3(256), 0, stream, current, m, bounds.as<Box4>(),
+                               nearest.as<uint32_t>());
+            hipLaunchKernelGGL(plocFlagKernel, dim3(grid), dim3(256), 0, stream, nearest.as<uint32_t>(), m,
+                               keep.as<uint32_t>(), merges.as<uint32_t>());
+            RT_TRY(exclusiveScanU32(keep.as<uint32_t>(), keep.as<uint32_t>(), static_cast<size_t>(m) + 1,
+                                    partials.as<uint32_t>(), stream));
+            RT_TRY(exclusiveScanU32(merges.as<uint32_t>(), merges.as<uint32_t>(), static_cast<size_t>(m) + 1,
+                                    partials.as<uint32_t>(), stream));
+            uint32_t totals[2] = {0, 0};
+            RT_HIP(hipMemcpyAsync(&totals[0], keep.as<uint32_t>() + m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipMemcpyAsync(&totals[1], merges.as<uint32_t>() + m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+            if (totals[1] == 0 || totals[0] + totals[1] != m || created + totals[1] > n - 1U)
+                return failInvalid("clustering made no progress");
+            const uint32_t idBase = (n - 1U) - created - totals[1];
+            hipLaunchKernelGGL(plocMergeKernel, dim3(grid), dim3(256), 0, stream, current, nearest.as<uint32_t>(),
+                               keep.as<uint32_t>(), merges.as<uint32_t>(), m, n, idBase, bounds.as<Box4>(),
+                               left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), counts, next);
+            created += totals[1];
+            m = totals[0];
+            std::swap(current, next);
+        }
+        if (created != n - 1U)
+            return failInvalid("clustering lost nodes");
+        const uint32_t none = kNoHit;
+        RT_HIP(hipMemcpyAsync(parent.data, &none, sizeof(none), hipMemcpyHostToDevice, stream));
+        uint32_t* reordered = idx[1 - result];
+        hipLaunchKernelGGL(plocLeafOrderKernel, dim3(blocks), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                           right.as<uint32_t>(), parent.as<uint32_t>(), counts, order, bounds.as<Box4>(),
+                           leafPosition.as<uint32_t>(), reordered, leafBounds.as<Box4>());
+        hipLaunchKernelGGL(plocRangeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                           right.as<uint32_t>(), parent.as<uint32_t>(), counts, first.as<uint32_t>(),
+                           last.as<uint32_t>());
+        hipLaunchKernelGGL(plocChildKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                           right.as<uint32_t>(), leafPosition.as<uint32_t>());
+        RT_HIP(hipMemcpyAsync(bounds.as<Box4>() + (n - 1U), leafBounds.data, sizeof(Box4) * n, hipMemcpyDeviceToDevice,
+                              stream));
+        RT_HIP(hipStreamSynchronize(stream));  // the scratch buffers of this block go out of scope
+        order = reordered;
+    } else if (n >= 2) {
         hipLaunchKernelGGL(radixTreeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, sortedKeys, n,
                            left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), first.as<uint32_t>(),
                            last.as<uint32_t>());

@@ -131,17 +131,16 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
 // slow rays per bounce instead of two.
 //
 // "The closest hit is that triangle" is decided without a closest-hit walk: the
-// shadow ray is intersected with the sampled triangle first (same arithmetic as
-// the traversal, so the same t), and the scene is then searched for ANY hit that
-// beats (t, instance, primitive) of that candidate - the first one found ends
-// the walk.  The outcome is the same bit for bit.
+// shade launch has intersected the shadow ray with the sampled triangle (same
+// arithmetic as the traversal, so the same t; lightTriangleDistance below) and
+// queued (t, instance, primitive) with the ray; the scene is then searched for
+// ANY hit that beats that candidate - the first one found ends the walk.  The
+// outcome is the same bit for bit.
 //
 // COUNT adds the visited nodes / tested triangles / entered instances to stats[4..6].
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(const WideNode* topNodes, const InstanceRecord* instances,
-                                                           const ShadeInstance* shadeInstances,
-                                                           const rt_hit_group_data* geometries, Buffers b, int which,
-                                                           int withShadow, uint4 limits) {
+                                                           Buffers b, int which, int withShadow, uint2 limits) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
     uint32_t spillRef[kPrivateStack];
@@ -168,43 +167,8 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
             const uint32_t ray = index - extendCount;
             const float4 o4 = b.shadowOrigin[ray];
             const float4 d4 = b.shadowDirection[ray];
-            const Ray world{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z};
-            float limit = d4.w;
-            uint32_t candidateInstance = kNoHit, candidatePrimitive = kNoHit;
-            if (__float_as_uint(b.shadowContribution[ray].w) & 4U) {
-                // the light's own triangle: where the ray meets it bounds the search
-                const uint2 target = b.shadowTarget[ray];
-                if (target.x >= limits.z || shadeInstances[target.x].geometry >= limits.w) {
-                    ++w.violations;
-                    return false;
-                }
-                const ShadeInstance& record = shadeInstances[target.x];
-                const rt_hit_group_data geometry = geometries[record.geometry];
-                const rt_uint3 triangle = geometry.indices[target.y];
-                const rt_float3 a = geometry.vertices[triangle.x].position;
-                const rt_float3 bb = geometry.vertices[triangle.y].position;
-                const rt_float3 c = geometry.vertices[triangle.z].position;
-                const float* m = record.toObject;
-                Ray local;
-                local.ox = ((m[0] * world.ox + m[1] * world.oy) + m[2] * world.oz) + m[3];
-                local.oy = ((m[4] * world.ox + m[5] * world.oy) + m[6] * world.oz) + m[7];
-                local.oz = ((m[8] * world.ox + m[9] * world.oy) + m[10] * world.oz) + m[11];
-                local.dx = (m[0] * world.dx + m[1] * world.dy) + m[2] * world.dz;
-                local.dy = (m[4] * world.dx + m[5] * world.dy) + m[6] * world.dz;
-                local.dz = (m[8] * world.dx + m[9] * world.dy) + m[10] * world.dz;
-                const Shear shear = makeShear(local);
-                float t, u, v;
-                if (!intersectTriangle(local, shear,
-                                       make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), 0U),
-                                       make_uint4(__float_as_uint(bb.x), __float_as_uint(bb.y), __float_as_uint(bb.z), 0U),
-                                       make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0U),
-                                       o4.w, limit, t, u, v))
-                    return false;  // the ray does not reach the sampled triangle at all
-                limit = t;
-                candidateInstance = target.x;
-                candidatePrimitive = target.y;
-            }
-            w.begin(world, o4.w, limit, candidateInstance, candidatePrimitive, true);
+            const uint2 target = b.shadowTarget[ray];  // kNoHit ids unless the ray is aimed at an emissive triangle
+            w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, target.x, target.y, true);
             return true;
         },
         [&](uint32_t index, const TraceResult& r) {
@@ -242,6 +206,35 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     }
 }
 
+// Where a shadow ray meets the emissive triangle it was aimed at, computed with
+// the arithmetic of the traversal (object-space ray, object-space vertices), so
+// that t equals what a closest-hit walk would report for that triangle bit for
+// bit.  False when the ray does not reach the triangle inside (tmin, tmax].
+__device__ inline bool lightTriangleDistance(const ShadeInstance* instances, const rt_hit_group_data* geometries,
+                                             uint32_t instance, uint32_t primitive, V3 origin, V3 direction, float tmin,
+                                             float tmax, float& distance) {
+    const ShadeInstance& record = instances[instance];
+    const rt_hit_group_data geometry = geometries[record.geometry];
+    const rt_uint3 triangle = geometry.indices[primitive];
+    const rt_float3 a = geometry.vertices[triangle.x].position;
+    const rt_float3 bb = geometry.vertices[triangle.y].position;
+    const rt_float3 c = geometry.vertices[triangle.z].position;
+    const float* m = record.toObject;
+    Ray local;
+    local.ox = ((m[0] * origin.x + m[1] * origin.y) + m[2] * origin.z) + m[3];
+    local.oy = ((m[4] * origin.x + m[5] * origin.y) + m[6] * origin.z) + m[7];
+    local.oz = ((m[8] * origin.x + m[9] * origin.y) + m[10] * origin.z) + m[11];
+    local.dx = (m[0] * direction.x + m[1] * direction.y) + m[2] * direction.z;
+    local.dy = (m[4] * direction.x + m[5] * direction.y) + m[6] * direction.z;
+    local.dz = (m[8] * direction.x + m[9] * direction.y) + m[10] * direction.z;
+    const Shear shear = makeShear(local);
+    float u, v;
+    return intersectTriangle(local, shear, make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), 0U),
+                             make_uint4(__float_as_uint(bb.x), __float_as_uint(bb.y), __float_as_uint(bb.z), 0U),
+                             make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), 0U), tmin, tmax,
+                             distance, u, v);
+}
+
 // One bounce of device.cu:908-1041 for every path of queue `which`.
 __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                            const rt_hit_group_data* geometries, Buffers b, int which,
@@ -257,7 +250,7 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     V3 origin{0, 0, 0}, direction{0, 0, 0};
     V3 shadowOrigin{0, 0, 0}, shadowDirection{0, 0, 0}, contribution{0, 0, 0};
     float shadowLimit = 0.0f;
-    uint32_t shadowBits = 0, targetInstance = 0, targetPrimitive = 0;
+    uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
     uint32_t path = 0;
     uint32_t gathered = 0, gatherQueries = 0;
 
@@ -336,10 +329,17 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
                     shadowOrigin = v3(hit.position) + normal * 0.001f;  // device.cu:550-552
                     shadowDirection = light.direction;
                     shadowLimit = light.delta ? light.distance - 0.002f : light.distance + 0.002f;
-                    const bool needsTriangle = !light.environment && !light.delta;
-                    shadowBits = lobe | (needsTriangle ? 4U : 0U);
-                    targetInstance = light.instance;
-                    targetPrimitive = light.primitive;
+                    shadowBits = lobe;
+                    if (!light.environment && !light.delta) {
+                        // the light's own triangle bounds the search (see traceKernel); a ray
+                        // that does not reach it at all cannot see the light
+                        targetInstance = light.instance;
+                        targetPrimitive = light.primitive;
+                        float distance = 0.0f;
+                        wantsShadow = lightTriangleDistance(instances, geometries, targetInstance, targetPrimitive,
+                                                            shadowOrigin, shadowDirection, 0.001f, shadowLimit, distance);
+                        shadowLimit = distance;
+                    }
                 }
             }
             b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -838,10 +838,9 @@ struct StageTimer {
 
 }  // namespace
 
-// Array sizes the ray stage checks references against: top-level nodes, instances, shading records, geometries.
-static uint4 limitsOf(const rt_scene* scene) {
-    return make_uint4(static_cast<uint32_t>(scene->nodeCount), scene->instanceCount, scene->shadeInstanceCount,
-                      scene->hitGroupCount);
+// Array sizes the ray stage checks references against: top-level nodes, instances.
+static uint2 limitsOf(const rt_scene* scene) {
+    return make_uint2(static_cast<uint32_t>(scene->nodeCount), scene->instanceCount);
 }
 
 static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
@@ -912,16 +911,16 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
         hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count,
                            seedSample, b);
     }
-    const uint4 limits = limitsOf(scene);
+    const uint2 limits = limitsOf(scene);
     // stage 1 is the ray stage (traceKernel), stage 3 the bookkeeping between bounces
     auto trace = [&](int which, int withShadow) {
         StageTimer timer(w, s, 1);
         if (counted)
             hipLaunchKernelGGL(traceKernel<true>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
-                               scene->shadeInstances, scene->hitGroups, b, which, withShadow, limits);
+                               b, which, withShadow, limits);
         else
             hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes, scene->instances,
-                               scene->shadeInstances, scene->hitGroups, b, which, withShadow, limits);
+                               b, which, withShadow, limits);
     };
     if (params->maxDepth > 0) {
         trace(0, 0);
@@ -961,7 +960,7 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
         const uint32_t count = std::min(b.capacity, emissionCount - done);
         const unsigned blocks = divUp(count, kShadeBlock);
         const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
-        const uint4 limits = limitsOf(scene);
+        const uint2 limits = limitsOf(scene);
         RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 4, s));
         RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
         hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, firstEmission + done,
@@ -969,7 +968,7 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
         for (uint32_t depth = 0; depth < 10U; ++depth) {
             const int which = depth & 1U;
             hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                               scene->instances, scene->shadeInstances, scene->hitGroups, b, which, 0, limits);
+                               scene->instances, b, which, 0, limits);
             hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
             hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);

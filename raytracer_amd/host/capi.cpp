@@ -204,6 +204,10 @@ int rth_renderer_set_sample_sequence(rt::Renderer* r, uint32_t first, uint32_t s
 int rth_renderer_set_pixel_range(rt::Renderer* r, uint32_t begin, uint32_t end) {
     return guarded([&] { r->setPixelRange(begin, end); });
 }
+int rth_renderer_set_concurrent_tiles(rt::Renderer* r, uint32_t count) {
+    return guarded([&] { r->setConcurrentTiles(count); });
+}
+uint32_t rth_renderer_concurrent_tiles(rt::Renderer* r) { return r->concurrentTiles(); }
 void rth_renderer_set_manual_photon_passes(rt::Renderer* r, int manual) { r->setManualPhotonPasses(manual != 0); }
 int rth_renderer_photon_pass_due(rt::Renderer* r) { return r->photonPassDue() ? 1 : 0; }
 int rth_renderer_begin_photon_pass(rt::Renderer* r) { return guarded([&] { r->beginPhotonPass(); }); }

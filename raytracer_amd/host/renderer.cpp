@@ -163,8 +163,7 @@ struct Renderer::Impl {
 
     ~Impl() {
         (void)hipDeviceSynchronize();
-        if (wavefront)
-            rt_wavefront_destroy(wavefront);
+        destroyTiles();
         if (sceneHandle)
             rt_scene_destroy(sceneHandle);
         for (auto& g : geometries)
@@ -200,7 +199,7 @@ struct Renderer::Impl {
         for (auto& buffer : aov)
             buffer.resize(pixels * sizeof(rt_float4));
         output.resize(pixels * sizeof(rt_uchar4));
-        engineCheck(rt_wavefront_create(static_cast<std::uint32_t>(pixels), &wavefront), "rt_wavefront_create");
+        createTiles(DefaultTiles);
         pixelBegin = 0;
         pixelEnd = static_cast<std::uint32_t>(pixels);
         causticsEnabled = profile == Profile::Final;  // renderer.cpp:251
@@ -509,7 +508,7 @@ struct Renderer::Impl {
     }
 
     std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count) {  // renderer.cpp:746-769
-        engineCheck(rt_trace_photons(wavefront, &launch, first, count, nullptr), "rt_trace_photons");
+        engineCheck(rt_trace_photons(tiles.front().wavefront, &launch, first, count, nullptr), "rt_trace_photons");
         hipCheck(hipDeviceSynchronize());
         std::uint32_t stored = 0;
         hipCheck(hipMemcpy(&stored, photonCounter.data(), sizeof(stored), hipMemcpyDeviceToHost));
@@ -557,9 +556,20 @@ struct Renderer::Impl {
         launch.composite = nullptr;
         launch.output = static_cast<rt_uchar4*>(target ? target : output.data());
         launch.sample = sample;
-        engineCheck(rt_render_sample_seeded(wavefront, &launch, pixelBegin, pixelEnd,
-                                            sampleFirst + sample * sampleStride, nullptr),
-                    "rt_render_sample");
+        // The pixel range is cut into one contiguous part per tile; the parts run
+        // on their own streams, so the slow rays that end one part's ray launch
+        // overlap with the other parts' work instead of idling the GPU.  The
+        // streams are ordinary (blocking) ones: work on the default stream before
+        // and after still orders against them.
+        const std::uint32_t count = pixelEnd - pixelBegin;
+        const std::uint32_t parts = static_cast<std::uint32_t>(tiles.size());
+        for (std::uint32_t k = 0; k < parts; ++k) {
+            const std::uint32_t begin = pixelBegin + static_cast<std::uint32_t>(std::uint64_t(count) * k / parts);
+            const std::uint32_t end = pixelBegin + static_cast<std::uint32_t>(std::uint64_t(count) * (k + 1) / parts);
+            engineCheck(rt_render_sample_seeded(tiles[k].wavefront, &launch, begin, end,
+                                                sampleFirst + sample * sampleStride, tiles[k].stream),
+                        "rt_render_sample");
+        }
         ++sample;
         photonPassPending = true;
     }
@@ -570,7 +580,40 @@ struct Renderer::Impl {
     std::uint32_t pixelBegin = 0, pixelEnd = 0;
     std::uint32_t sampleFirst = 0, sampleStride = 1;
     rt_scene* sceneHandle = nullptr;
-    rt_wavefront* wavefront = nullptr;
+    // Wavefront state and stream per concurrent part of the frame.
+    struct Tile {
+        rt_wavefront* wavefront = nullptr;
+        hipStream_t stream = nullptr;
+    };
+    static constexpr std::uint32_t DefaultTiles = 2;
+    std::vector<Tile> tiles;
+    std::uint32_t measurementFlags = 0;
+
+    void destroyTiles() {
+        for (auto& t : tiles) {
+            if (t.wavefront)
+                rt_wavefront_destroy(t.wavefront);
+            if (t.stream)
+                (void)hipStreamDestroy(t.stream);
+        }
+        tiles.clear();
+    }
+
+    void createTiles(std::uint32_t count) {
+        hipCheck(hipDeviceSynchronize());
+        destroyTiles();
+        const std::size_t pixels = static_cast<std::size_t>(width) * height;
+        count = std::max<std::uint32_t>(1U, std::min<std::uint32_t>(count, 8U));
+        const std::size_t capacity = (pixels + count - 1) / count;
+        tiles.resize(count);
+        for (auto& t : tiles) {
+            engineCheck(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &t.wavefront), "rt_wavefront_create");
+            engineCheck(rt_wavefront_configure(t.wavefront, measurementFlags), "rt_wavefront_configure");
+            if (count > 1)
+                hipCheck(hipStreamCreate(&t.stream));  // a single tile stays on the default stream
+        }
+    }
+
     std::vector<GeometryState> geometries;
     std::vector<ImageState> images;
     Buffer materials, textures, lights, environment, environmentCdf;
@@ -669,16 +712,38 @@ void* Renderer::accumulationBuffer(int index) const {
     return impl_->aov[index].data();
 }
 void Renderer::statistics(std::uint64_t out[8]) {
-    engineCheck(rt_wavefront_stats(impl_->wavefront, out, 1, nullptr), "rt_wavefront_stats");
+    for (int k = 0; k < 8; ++k)
+        out[k] = 0;
+    for (auto& t : impl_->tiles) {
+        std::uint64_t part[8] = {};
+        engineCheck(rt_wavefront_stats(t.wavefront, part, 1, t.stream), "rt_wavefront_stats");
+        for (int k = 0; k < 8; ++k)
+            out[k] += part[k];
+    }
 }
 void Renderer::setMeasurement(bool timeStages, bool countTraversal) {
-    engineCheck(rt_wavefront_configure(impl_->wavefront, (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) |
-                                                             (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U)),
-                "rt_wavefront_configure");
+    impl_->measurementFlags =
+        (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) | (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U);
+    for (auto& t : impl_->tiles)
+        engineCheck(rt_wavefront_configure(t.wavefront, impl_->measurementFlags), "rt_wavefront_configure");
 }
 void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
-    engineCheck(rt_wavefront_timings(impl_->wavefront, milliseconds, launches, nullptr), "rt_wavefront_timings");
+    for (int k = 0; k < 5; ++k) {
+        milliseconds[k] = 0.0f;
+        launches[k] = 0;
+    }
+    for (auto& t : impl_->tiles) {
+        float ms[5] = {};
+        std::uint32_t n[5] = {};
+        engineCheck(rt_wavefront_timings(t.wavefront, ms, n, t.stream), "rt_wavefront_timings");
+        for (int k = 0; k < 5; ++k) {
+            milliseconds[k] += ms[k];
+            launches[k] += n[k];
+        }
+    }
 }
+void Renderer::setConcurrentTiles(std::uint32_t count) { impl_->createTiles(count); }
+std::uint32_t Renderer::concurrentTiles() const { return static_cast<std::uint32_t>(impl_->tiles.size()); }
 void Renderer::synchronize() const { hipCheck(hipDeviceSynchronize()); }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }
 float Renderer::causticRadius() const { return impl_->causticRadius; }

@@ -49,6 +49,11 @@ public:
     void setSampleSequence(std::uint32_t first, std::uint32_t stride);
     // Restricts render() to the pixels [begin, end) in row-major order.
     void setPixelRange(std::uint32_t begin, std::uint32_t end);
+    // render() cuts its pixel range into `count` parts (1..8, default 2) that run
+    // concurrently on streams of their own; the image does not depend on it.
+    // With more than one part the stage timings of the parts overlap in time.
+    void setConcurrentTiles(std::uint32_t count);
+    std::uint32_t concurrentTiles() const;
     // Splits a photon pass: render() then no longer runs it by itself; the
     // driver calls beginPhotonPass(), tracePhotonRange() for its share, places
     // the other ranks' photons behind its own in photonBuffer() and calls

@@ -97,6 +97,8 @@ _SIG = {
     "rth_renderer_set_photon_budget": (C.c_int, [_vp, _u32, _u32, _u32]),
     "rth_renderer_set_sample_sequence": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_pixel_range": (C.c_int, [_vp, _u32, _u32]),
+    "rth_renderer_set_concurrent_tiles": (C.c_int, [_vp, _u32]),
+    "rth_renderer_concurrent_tiles": (_u32, [_vp]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
     "rth_renderer_begin_photon_pass": (C.c_int, [_vp]),
@@ -258,6 +260,12 @@ class Renderer:
 
     def set_pixel_range(self, begin, end):
         _check(load().rth_renderer_set_pixel_range(self.handle, begin, end))
+
+    def set_concurrent_tiles(self, count):
+        _check(load().rth_renderer_set_concurrent_tiles(self.handle, count))
+
+    def concurrent_tiles(self):
+        return int(load().rth_renderer_concurrent_tiles(self.handle))
 
     def set_manual_photon_passes(self, manual=True):
         load().rth_renderer_set_manual_photon_passes(self.handle, int(manual))

@@ -82,6 +82,18 @@ def test_soup_incoherent(engine, oracle):
     assert s.triangleCount == 100000 and s.nodeCount > 1000
 
 
+def test_clustering_builder_gives_the_same_hits(engine, oracle, monkeypatch):
+    """RT_BLAS_BUILDER=ploc selects the locally-ordered clustering build; hits do not depend on the tree."""
+    monkeypatch.setenv("RT_BLAS_BUILDER", "ploc")
+    scene = workloads.triangle_soup(50000, seed=9)
+    check_scene(engine, oracle, scene, workloads.random_rays(scene, 100000, seed=3))
+    scene = workloads.sphere_field(count=50, subdivisions=2)
+    check_scene(engine, oracle, scene, workloads.random_rays(scene, 50000, seed=6))
+    for n in (1, 2, 3, 5, 9):
+        scene = workloads.triangle_soup(n, seed=n)
+        check_scene(engine, oracle, scene, workloads.random_rays(scene, 2000, seed=n), brute=True)
+
+
 def test_instanced_sphere_field(engine, oracle):
     scene = workloads.sphere_field(count=300, subdivisions=3)
     o1, d1 = workloads.camera_rays(scene, 320, 180)
