@@ -123,23 +123,27 @@ def cpu_baseline(scene, args, width, height, profile):
     threads = min(16, os.cpu_count() or 1)
     setup = Setup(scene, width, height, final=False)  # preview path lengths; no photon map on the CPU leg
     setup.params.sample = 0
-    mid = height // 2
+    # probe: one sample of the middle half of the frame; then as many further samples of the same
+    # rows as fit the time budget (each sample index draws new random streams, like the GPU's steps)
+    rows = height // 2
+    first = (height - rows) // 2
     orc.ray_counter(reset=True)
     t1 = time.perf_counter()
-    ref.render_sample(setup.params, mid * width, (mid + 2) * width, threads)
+    ref.render_sample(setup.params, first * width, (first + rows) * width, threads)
     probe_s = time.perf_counter() - t1
     probe_rays = orc.ray_counter(reset=True)
-    rows = int(max(2, min(height // 2, 2 * args.cpu_seconds / max(probe_s, 1e-6))))
-    first = (height - rows) // 2
+    samples = int(max(1, min(64, args.cpu_seconds / max(probe_s, 1e-3))))
     t1 = time.perf_counter()
-    ref.render_sample(setup.params, first * width, (first + rows) * width, threads)
+    for k in range(samples):
+        setup.params.sample = 1 + k
+        ref.render_sample(setup.params, first * width, (first + rows) * width, threads)
     cpu_s = time.perf_counter() - t1
     rays = orc.ray_counter(reset=True)
     return {
         "value": rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"{rows} pixel rows ({rows * width} paths, {rays} rays) from the middle of the same frame, "
-                  f"sample 0, preview depth, the oracle's integrator over its own BVH, {threads} std::thread workers "
-                  f"(probe: {probe_rays} rays in {probe_s:.2f} s)",
+        "sample": f"{samples} samples of {rows} pixel rows ({samples * rows * width} paths, {rays} rays) from the middle "
+                  f"of the same frame, preview depth, the oracle's integrator over its own BVH, {threads} std::thread "
+                  f"workers, {cpu_s:.1f} s (probe: {probe_rays} rays in {probe_s:.2f} s)",
     }
 
 

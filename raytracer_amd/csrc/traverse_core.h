@@ -586,6 +586,9 @@ template <bool COUNT, typename Fetch, typename Store>
 __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Fetch&& fetch, Store&& store) {
     bool active = false;
     uint32_t rayIndex = 0;
+#ifdef RT_TRACE_STEP_CAP
+    int turns = 0;
+#endif
     for (;;) {
         const unsigned long long idleMask = __ballot(!active);
         if (!feed.drained() && __popcll(idleMask) >= RT_TRACE_REFILL) {
@@ -622,7 +625,14 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
                 }
             }
         }
+#ifdef RT_TRACE_STEP_CAP  // experiment only: rays give up after this many turns
+        if (active && ++turns > RT_TRACE_STEP_CAP)
+            walk.node = kDone;
+#endif
         if (active && walk.node == kDone) {
+#ifdef RT_TRACE_STEP_CAP
+            turns = 0;
+#endif
             store(rayIndex, walk.result());
             active = false;
 #ifdef RT_TRACE_PROFILE
