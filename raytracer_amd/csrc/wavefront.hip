@@ -81,6 +81,22 @@ __device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t*
 
 // ---- camera paths -----------------------------------------------------------
 
+// Pixel of path i of a launch over [pixelBegin, pixelBegin + count).  Paths are
+// numbered tile by tile (8 x 8 pixels) over the full eight-row bands of the
+// range, so the 64 lanes of a wave hold a compact patch of the image: their rays
+// walk the same nodes and their photon queries the same cells.  Rows left over
+// at the end, and ranges that do not start on a row, keep row-major order.  Only
+// the numbering of paths changes; a pixel's random streams depend on its own index.
+__device__ inline uint32_t pixelOfPath(uint32_t i, uint32_t pixelBegin, uint32_t count, uint32_t width) {
+    if (pixelBegin % width != 0U || width % 8U != 0U)
+        return pixelBegin + i;
+    const uint32_t band = 8U * width;
+    if (i >= count / band * band)
+        return pixelBegin + i;
+    const uint32_t inBand = i % band, tile = inBand / 64U, within = inBand % 64U;
+    return pixelBegin + (i - inBand) + (within / 8U) * width + tile * 8U + within % 8U;
+}
+
 // device.cu:882-906: one path per pixel of [pixelBegin, pixelBegin + count)
 __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p, uint32_t pixelBegin, uint32_t count,
                                                               uint32_t seedSample, Buffers b) {
@@ -92,7 +108,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     }
     if (i >= count)
         return;
-    const uint32_t index = pixelBegin + i;
+    const uint32_t index = pixelOfPath(i, pixelBegin, count, p.width);
     const uint32_t px = index % p.width, py = index / p.width;
     uint32_t rng = index * 9781U + seedSample * 6271U + 0x68bc21ebU;
     const float jx = random01(rng);
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
         return;
-    const uint32_t index = pixelBegin + i;
+    const uint32_t index = pixelOfPath(i, pixelBegin, count, p.width);
     const float weight = 1.0f / static_cast<float>(p.sample + 1U);
     const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
     const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);

@@ -164,6 +164,8 @@ struct Renderer::Impl {
     ~Impl() {
         (void)hipDeviceSynchronize();
         destroyTiles();
+        if (photonWavefront)
+            rt_wavefront_destroy(photonWavefront);
         if (sceneHandle)
             rt_scene_destroy(sceneHandle);
         for (auto& g : geometries)
@@ -508,7 +510,19 @@ struct Renderer::Impl {
     }
 
     std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count) {  // renderer.cpp:746-769
-        engineCheck(rt_trace_photons(tiles.front().wavefront, &launch, first, count, nullptr), "rt_trace_photons");
+        // The photon pass has wavefront state of its own, sized for a whole pass (at
+        // most 2^24 paths, 328 bytes each): every batch ends with the drain of its
+        // ray launches, so few large batches beat many frame-sized ones.
+        const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
+        if (!photonWavefront || photonWavefrontCapacity < wanted) {
+            hipCheck(hipDeviceSynchronize());
+            if (photonWavefront)
+                rt_wavefront_destroy(photonWavefront);
+            photonWavefront = nullptr;
+            engineCheck(rt_wavefront_create(wanted, &photonWavefront), "rt_wavefront_create");
+            photonWavefrontCapacity = wanted;
+        }
+        engineCheck(rt_trace_photons(photonWavefront, &launch, first, count, nullptr), "rt_trace_photons");
         hipCheck(hipDeviceSynchronize());
         std::uint32_t stored = 0;
         hipCheck(hipMemcpy(&stored, photonCounter.data(), sizeof(stored), hipMemcpyDeviceToHost));
@@ -587,6 +601,8 @@ struct Renderer::Impl {
     };
     static constexpr std::uint32_t DefaultTiles = 2;
     std::vector<Tile> tiles;
+    rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
+    std::uint32_t photonWavefrontCapacity = 0;
     std::uint32_t measurementFlags = 0;
 
     void destroyTiles() {
@@ -717,6 +733,12 @@ void Renderer::statistics(std::uint64_t out[8]) {
     for (auto& t : impl_->tiles) {
         std::uint64_t part[8] = {};
         engineCheck(rt_wavefront_stats(t.wavefront, part, 1, t.stream), "rt_wavefront_stats");
+        for (int k = 0; k < 8; ++k)
+            out[k] += part[k];
+    }
+    if (impl_->photonWavefront) {
+        std::uint64_t part[8] = {};
+        engineCheck(rt_wavefront_stats(impl_->photonWavefront, part, 1, nullptr), "rt_wavefront_stats");
         for (int k = 0; k < 8; ++k)
             out[k] += part[k];
     }

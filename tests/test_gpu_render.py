@@ -185,3 +185,22 @@ def test_pixel_ranges_compose_to_the_full_frame(R):
         parts.render()
     a = parts.linear_pixels().reshape(-1, 4)[: w * h // 3]
     assert np.array_equal(a, full.linear_pixels().reshape(-1, 4)[: w * h // 3])
+
+
+def test_concurrent_tiles_do_not_change_the_image(R):
+    """render() cut into 1, 2 or 5 concurrent parts (own streams, own wavefront state) gives bit-identical
+    buffers; 72 rows exercise full 8-row bands, leftover rows and parts that start inside a band."""
+    scene = workloads.cornell_box(light="panel")
+    w, h = 64, 72
+    images = []
+    for tiles in (1, 2, 5):
+        r = R.Renderer(scene, w, h)
+        r.set_concurrent_tiles(tiles)
+        assert r.concurrent_tiles() == tiles
+        for _ in range(3):
+            r.render()
+        images.append((r.linear_pixels().copy(), r.pixels().copy(), r.statistics()))
+    for pixels, bytes8, stats in images[1:]:
+        assert np.array_equal(pixels, images[0][0])
+        assert np.array_equal(bytes8, images[0][1])
+        assert stats["extend_rays"] == images[0][2]["extend_rays"] and stats["refused_references"] == 0
