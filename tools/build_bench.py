@@ -37,6 +37,10 @@ def one(name, scene, builder, rays=1 << 21):
 
 def main():
     engine.load()
+    if len(sys.argv) > 1:  # soup sizes on the command line, default builder only: the large-scene measurements
+        for n in (int(a) for a in sys.argv[1:]):
+            one(f"soup {n}", workloads.triangle_soup(n), "radix", rays=1 << 24)
+        return
     cases = [("tube 871k", workloads.dragon_cornell()), ("soup 100k", workloads.triangle_soup(100000)),
              ("soup 1M", workloads.triangle_soup(1000000)), ("spheres", workloads.sphere_field())]
     for name, scene in cases:
