@@ -5,8 +5,11 @@
 
 #include "rt_types.h"
 
+#include <cstdio>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
+#include <vector>
 #include <string>
 
 namespace {
@@ -153,6 +156,175 @@ void rth_scene_set_environment(rt::Scene* scene, const float* rgba, uint32_t wid
     e.rotation = rotation;
     e.strength = strength;
     e.exposure = exposure;
+}
+
+// ---- scene files and read access (tests, tools) ----------------------------
+
+rt::Scene* rth_scene_load(const char* path) {
+    rt::Scene* scene = nullptr;
+    guarded([&] { scene = new rt::Scene(rt::loadScene(path)); });
+    return scene;
+}
+
+// counts8: geometries, instances, materials, images, textures, cameras, lights, environment pixels
+void rth_scene_counts(const rt::Scene* scene, uint32_t* counts8) {
+    counts8[0] = static_cast<uint32_t>(scene->geometries.size());
+    counts8[1] = static_cast<uint32_t>(scene->instances.size());
+    counts8[2] = static_cast<uint32_t>(scene->materials.size());
+    counts8[3] = static_cast<uint32_t>(scene->images.size());
+    counts8[4] = static_cast<uint32_t>(scene->textures.size());
+    counts8[5] = static_cast<uint32_t>(scene->cameras.size());
+    counts8[6] = static_cast<uint32_t>(scene->lights.size());
+    counts8[7] = static_cast<uint32_t>(scene->environment.pixels.size());
+}
+
+// sizes3: vertices, indices, material.  With non-null pointers also copies the
+// vertices (14 floats each: position, normal, tangent, uv, uv1) and the indices.
+int rth_scene_get_geometry(const rt::Scene* scene, uint32_t index, uint32_t* sizes3, float* vertices14,
+                           uint32_t* indices, char* name, uint32_t nameBytes) {
+    return guarded([&] {
+        const rt::Geometry& g = scene->geometries.at(index);
+        sizes3[0] = static_cast<uint32_t>(g.vertices.size());
+        sizes3[1] = static_cast<uint32_t>(g.indices.size());
+        sizes3[2] = g.material;
+        static_assert(sizeof(rt::Vertex) == 14 * sizeof(float), "Vertex is 14 packed floats");
+        if (vertices14)
+            std::memcpy(vertices14, g.vertices.data(), g.vertices.size() * sizeof(rt::Vertex));
+        if (indices)
+            std::memcpy(indices, g.indices.data(), g.indices.size() * sizeof(uint32_t));
+        if (name && nameBytes)
+            std::snprintf(name, nameBytes, "%s", g.name.c_str());
+    });
+}
+
+int rth_scene_get_instance(const rt::Scene* scene, uint32_t index, float* m16, uint32_t* geometry) {
+    return guarded([&] {
+        const rt::Instance& i = scene->instances.at(index);
+        std::memcpy(m16, i.transform.values.data(), sizeof(float) * 16);
+        *geometry = i.geometry;
+    });
+}
+
+// The material in rt_gpu_material layout (what rth_scene_add_material takes) plus alphaCutoff and flags.
+int rth_scene_get_material(const rt::Scene* scene, uint32_t index, rt_gpu_material* out, float* alphaCutoff,
+                           uint32_t* flags) {
+    return guarded([&] {
+        const rt::Material& m = scene->materials.at(index);
+        std::memset(out, 0, sizeof(*out));
+        auto ref = [](const rt::TextureRef& t) {
+            rt_gpu_texture_ref r{};
+            r.texture = t.texture;
+            r.texCoord = t.texCoord;
+            r.offset = {t.offset.x, t.offset.y};
+            r.scale = {t.scale.x, t.scale.y};
+            r.rotation = t.rotation;
+            r.strength = t.strength;
+            return r;
+        };
+        out->baseColor = {m.baseColor.x, m.baseColor.y, m.baseColor.z, m.baseColor.w};
+        out->emissive = {m.emissive.x, m.emissive.y, m.emissive.z};
+        out->attenuationColor = {m.attenuationColor.x, m.attenuationColor.y, m.attenuationColor.z};
+        out->metallic = m.metallic;
+        out->roughness = m.roughness;
+        out->transmission = m.transmission;
+        out->ior = m.ior;
+        out->thickness = m.thickness;
+        out->attenuationDistance = m.attenuationDistance;
+        out->emissiveStrength = m.emissiveStrength;
+        out->dispersion = m.dispersion;
+        out->baseColorTexture = ref(m.baseColorTexture);
+        out->metallicRoughnessTexture = ref(m.metallicRoughnessTexture);
+        out->normalTexture = ref(m.normalTexture);
+        out->emissiveTexture = ref(m.emissiveTexture);
+        out->transmissionTexture = ref(m.transmissionTexture);
+        out->thicknessTexture = ref(m.thicknessTexture);
+        *alphaCutoff = m.alphaCutoff;
+        *flags = m.flags;
+    });
+}
+
+// values8: verticalFov, aspectRatio, nearPlane, farPlane, aperture, focusDistance, 0, 0
+int rth_scene_get_camera(const rt::Scene* scene, uint32_t index, float* m16, float* values8) {
+    return guarded([&] {
+        const rt::Camera& c = scene->cameras.at(index);
+        std::memcpy(m16, c.transform.values.data(), sizeof(float) * 16);
+        const float values[8] = {c.verticalFov, c.aspectRatio, c.nearPlane, c.farPlane, c.aperture, c.focusDistance, 0, 0};
+        std::memcpy(values8, values, sizeof(values));
+    });
+}
+
+// values8: color rgb, intensity, range, innerCone, outerCone, type
+int rth_scene_get_light(const rt::Scene* scene, uint32_t index, float* m16, float* values8) {
+    return guarded([&] {
+        const rt::Light& l = scene->lights.at(index);
+        std::memcpy(m16, l.transform.values.data(), sizeof(float) * 16);
+        const float values[8] = {l.color.x, l.color.y, l.color.z, l.intensity,
+                                 l.range, l.innerCone, l.outerCone, static_cast<float>(l.type)};
+        std::memcpy(values8, values, sizeof(values));
+    });
+}
+
+// sizes4: width, height, mimeType, encoded bytes.  rgba (width * height * 4 bytes) is filled when not null.
+int rth_scene_get_image(const rt::Scene* scene, uint32_t index, uint32_t* sizes4, uint8_t* rgba) {
+    return guarded([&] {
+        const rt::Image& i = scene->images.at(index);
+        sizes4[0] = i.width;
+        sizes4[1] = i.height;
+        sizes4[2] = i.mimeType;
+        sizes4[3] = static_cast<uint32_t>(i.encoded.size());
+        if (rgba)
+            std::memcpy(rgba, i.rgba.data(), i.rgba.size());
+    });
+}
+
+// values6: image, magFilter, minFilter, wrapU, wrapV, 0
+int rth_scene_get_texture(const rt::Scene* scene, uint32_t index, int32_t* values6) {
+    return guarded([&] {
+        const rt::Texture& t = scene->textures.at(index);
+        values6[0] = t.image;
+        values6[1] = static_cast<int32_t>(t.magFilter);
+        values6[2] = static_cast<int32_t>(t.minFilter);
+        values6[3] = static_cast<int32_t>(t.wrapU);
+        values6[4] = static_cast<int32_t>(t.wrapV);
+        values6[5] = 0;
+    });
+}
+
+// values5: width, height, rotation, strength, exposure.  pixels (RGBA float) is filled when not null.
+int rth_scene_get_environment(const rt::Scene* scene, float* values5, float* pixels) {
+    return guarded([&] {
+        const rt::Environment& e = scene->environment;
+        values5[0] = static_cast<float>(e.width);
+        values5[1] = static_cast<float>(e.height);
+        values5[2] = e.rotation;
+        values5[3] = e.strength;
+        values5[4] = e.exposure;
+        if (pixels)
+            std::memcpy(pixels, e.pixels.data(), e.pixels.size() * sizeof(rt::Vec4));
+    });
+}
+
+// The loader's image readers on a byte buffer: returns 0 and the size; call again with `out` to get the pixels.
+int rth_decode_png(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height, uint8_t* out) {
+    return guarded([&] {
+        std::vector<std::byte> file(reinterpret_cast<const std::byte*>(bytes), reinterpret_cast<const std::byte*>(bytes) + size);
+        std::vector<std::uint8_t> rgba;
+        if (!rt::decodePngImage(file, rgba, *width, *height))
+            throw std::runtime_error("not a PNG this reader handles");
+        if (out)
+            std::memcpy(out, rgba.data(), rgba.size());
+    });
+}
+
+int rth_decode_hdr(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height, float* out) {
+    return guarded([&] {
+        std::vector<std::byte> file(reinterpret_cast<const std::byte*>(bytes), reinterpret_cast<const std::byte*>(bytes) + size);
+        std::vector<rt::Vec4> pixels;
+        if (!rt::decodeRadianceImage(file, pixels, *width, *height))
+            throw std::runtime_error("not a Radiance .hdr file this reader handles");
+        if (out)
+            std::memcpy(out, pixels.data(), pixels.size() * sizeof(rt::Vec4));
+    });
 }
 
 rt::Renderer* rth_renderer_create(const rt::Scene* scene, uint32_t width, uint32_t height, int finalProfile) {

@@ -140,4 +140,21 @@ struct Scene {
     Environment environment;
 };
 
+// glTF 2.0 (.gltf with external or embedded buffers, or .glb), as the
+// reference's loadScene (src/scene.hpp:145, src/scene.cpp:332-406): TRIANGLES
+// primitives, KHR_lights_punctual, the KHR_materials_{ior, transmission, volume,
+// dispersion, emissive_strength, unlit} and KHR_texture_transform extensions,
+// KHR_mesh_quantization attributes, the `raytracer_*` extras.  PNG images come
+// back decoded (Image::rgba); other formats keep their encoded bytes.  The
+// environment named by `raytracer_hdri` must be a Radiance .hdr file.
+Scene loadScene(const std::filesystem::path& path);
+
+// The two image readers the loader uses, exposed for tests and tools.
+// PNG -> RGBA8, row 0 = top row; false when the file is not a PNG this reader handles.
+bool decodePngImage(const std::vector<std::byte>& file, std::vector<std::uint8_t>& rgba, std::uint32_t& width,
+                    std::uint32_t& height);
+// Radiance RGBE -> float RGBA (alpha 1), rows in file order.
+bool decodeRadianceImage(const std::vector<std::byte>& file, std::vector<Vec4>& pixels, std::uint32_t& width,
+                         std::uint32_t& height);
+
 }  // namespace rt

@@ -84,6 +84,18 @@ _SIG = {
     "rth_scene_add_image": (C.c_int, [_vp, _vp, _u32, _u32]),
     "rth_scene_add_texture": (C.c_int, [_vp, C.c_int32, _u32, _u32]),
     "rth_scene_set_environment": (None, [_vp, _vp, _u32, _u32, _f32, _f32, _f32]),
+    "rth_scene_load": (_vp, [C.c_char_p]),
+    "rth_scene_counts": (None, [_vp, C.POINTER(_u32)]),
+    "rth_scene_get_geometry": (C.c_int, [_vp, _u32, C.POINTER(_u32), _vp, _vp, C.c_char_p, _u32]),
+    "rth_scene_get_instance": (C.c_int, [_vp, _u32, _vp, C.POINTER(_u32)]),
+    "rth_scene_get_material": (C.c_int, [_vp, _u32, _vp, C.POINTER(_f32), C.POINTER(_u32)]),
+    "rth_scene_get_camera": (C.c_int, [_vp, _u32, _vp, _vp]),
+    "rth_scene_get_light": (C.c_int, [_vp, _u32, _vp, _vp]),
+    "rth_scene_get_image": (C.c_int, [_vp, _u32, C.POINTER(_u32), _vp]),
+    "rth_scene_get_texture": (C.c_int, [_vp, _u32, _vp]),
+    "rth_scene_get_environment": (C.c_int, [_vp, _vp, _vp]),
+    "rth_decode_png": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
+    "rth_decode_hdr": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
     "rth_renderer_create": (_vp, [_vp, _u32, _u32, C.c_int]),
     "rth_renderer_destroy": (None, [_vp]),
     "rth_renderer_render": (C.c_int, [_vp, _vp]),
@@ -207,6 +219,104 @@ class HostScene:
             self.close()
         except Exception:
             pass
+
+
+class LoadedScene(HostScene):
+    """rt::Scene read from a .gltf / .glb file by rt::loadScene, with read access to what it holds."""
+
+    def __init__(self, path):
+        lib = load()
+        handle = lib.rth_scene_load(os.fsencode(str(path)))
+        if not handle:
+            raise engine.EngineError(lib.rth_last_error().decode())
+        self.handle = C.c_void_p(handle)
+
+    def counts(self):
+        out = (_u32 * 8)()
+        load().rth_scene_counts(self.handle, out)
+        keys = ("geometries", "instances", "materials", "images", "textures", "cameras", "lights", "environment_pixels")
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def geometry(self, index):
+        lib = load()
+        sizes = (_u32 * 3)()
+        name = C.create_string_buffer(256)
+        _check(lib.rth_scene_get_geometry(self.handle, index, sizes, None, None, name, 256))
+        vertices = np.empty((sizes[0], 14), dtype=np.float32)
+        indices = np.empty(sizes[1], dtype=np.uint32)
+        _check(lib.rth_scene_get_geometry(self.handle, index, sizes, _p(vertices), _p(indices), name, 256))
+        return dict(name=name.value.decode(), vertices=vertices, indices=indices.reshape(-1, 3), material=int(sizes[2]))
+
+    def instance(self, index):
+        m = np.empty(16, dtype=np.float32)
+        g = _u32(0)
+        _check(load().rth_scene_get_instance(self.handle, index, _p(m), C.byref(g)))
+        return int(g.value), m
+
+    def material(self, index):
+        m = GpuMaterial()
+        cutoff, flags = _f32(0), _u32(0)
+        _check(load().rth_scene_get_material(self.handle, index, C.byref(m), C.byref(cutoff), C.byref(flags)))
+        return m, float(cutoff.value), int(flags.value)
+
+    def camera(self, index):
+        m, v = np.empty(16, dtype=np.float32), np.empty(8, dtype=np.float32)
+        _check(load().rth_scene_get_camera(self.handle, index, _p(m), _p(v)))
+        return dict(transform=m, verticalFov=float(v[0]), aspectRatio=float(v[1]), nearPlane=float(v[2]),
+                    farPlane=float(v[3]), aperture=float(v[4]), focusDistance=float(v[5]))
+
+    def light(self, index):
+        m, v = np.empty(16, dtype=np.float32), np.empty(8, dtype=np.float32)
+        _check(load().rth_scene_get_light(self.handle, index, _p(m), _p(v)))
+        return dict(transform=m, color=v[:3].copy(), intensity=float(v[3]), range=float(v[4]), innerCone=float(v[5]),
+                    outerCone=float(v[6]), type=int(v[7]))
+
+    def image(self, index):
+        sizes = (_u32 * 4)()
+        _check(load().rth_scene_get_image(self.handle, index, sizes, None))
+        rgba = np.empty((sizes[1], sizes[0], 4), dtype=np.uint8)
+        _check(load().rth_scene_get_image(self.handle, index, sizes, _p(rgba)))
+        return dict(width=int(sizes[0]), height=int(sizes[1]), mimeType=int(sizes[2]), encoded_bytes=int(sizes[3]), rgba=rgba)
+
+    def texture(self, index):
+        v = np.empty(6, dtype=np.int32)
+        _check(load().rth_scene_get_texture(self.handle, index, _p(v)))
+        return dict(image=int(v[0]), magFilter=int(v[1]), minFilter=int(v[2]), wrapU=int(v[3]), wrapV=int(v[4]))
+
+    def environment(self):
+        v = np.empty(5, dtype=np.float32)
+        _check(load().rth_scene_get_environment(self.handle, _p(v), None))
+        pixels = np.empty((int(v[1]), int(v[0]), 4), dtype=np.float32)
+        _check(load().rth_scene_get_environment(self.handle, _p(v), _p(pixels)))
+        return dict(width=int(v[0]), height=int(v[1]), rotation=float(v[2]), strength=float(v[3]),
+                    exposure=float(v[4]), pixels=pixels)
+
+
+def load_scene(path):
+    """rt::loadScene: a .gltf / .glb file as a scene a Renderer accepts."""
+    return LoadedScene(path)
+
+
+def decode_png(data):
+    """The loader's PNG reader on a bytes object: (height, width, 4) uint8."""
+    lib = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = _u32(0), _u32(0)
+    _check(lib.rth_decode_png(_p(buf), buf.size, C.byref(w), C.byref(h), None))
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    _check(lib.rth_decode_png(_p(buf), buf.size, C.byref(w), C.byref(h), _p(out)))
+    return out
+
+
+def decode_hdr(data):
+    """The loader's Radiance .hdr reader on a bytes object: (height, width, 4) float32."""
+    lib = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = _u32(0), _u32(0)
+    _check(lib.rth_decode_hdr(_p(buf), buf.size, C.byref(w), C.byref(h), None))
+    out = np.empty((h.value, w.value, 4), dtype=np.float32)
+    _check(lib.rth_decode_hdr(_p(buf), buf.size, C.byref(w), C.byref(h), _p(out)))
+    return out
 
 
 class Renderer:

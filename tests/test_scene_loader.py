@@ -1,0 +1,317 @@
+"""CPU tests of the glTF / GLB scene loader (rt::loadScene of the host library), the next row after the
+hot path: a scene written by tests/gltf_writer.py must come back field for field, in every container;
+the PNG and Radiance readers are checked against encoders / decoders restated here in numpy, and against
+the image files the reference ships when they are present on this machine.
+
+Parity status: the reference loads through fastgltf + stb_image, neither of which is available here, and
+holds no loader tests or golden scenes; the field mapping is pinned by the citations in host/scene.cpp,
+the decoders by the format definitions restated below ("parity unpinned" against upstream's binaries)."""
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from raytracer_amd import engine, workloads
+from gltf_writer import encode_hdr, encode_png, float_to_rgbe, rgbe_to_float, write_scene
+
+
+@pytest.fixture(scope="module")
+def R():
+    from raytracer_amd import renderer
+    renderer.load()
+    return renderer
+
+
+def expect_same_scene(loaded, scene):
+    counts = loaded.counts()
+    assert counts["geometries"] == len(scene["geometries"])
+    assert counts["instances"] == len(scene["instances"])
+    assert counts["materials"] == len(scene["materials"])
+    assert counts["cameras"] == len(scene["cameras"]) and counts["lights"] == len(scene["lights"])
+    for k, g in enumerate(scene["geometries"]):
+        got = loaded.geometry(k)
+        v = np.asarray(g["vertices"], dtype=np.float32)
+        packed = np.concatenate([v[:, 0:3], v[:, 3:6], v[:, 8:12], v[:, 12:14], v[:, 14:16]], axis=1)
+        assert np.array_equal(got["vertices"].view(np.uint32), packed.view(np.uint32))
+        assert np.array_equal(got["indices"], np.asarray(g["indices"], dtype=np.uint32).reshape(-1, 3))
+        assert got["material"] == g["material"] and got["name"] == f"mesh.0"
+    for k, (gi, m) in enumerate(scene["instances"]):
+        geometry, matrix = loaded.instance(k)
+        assert geometry == gi and np.array_equal(matrix, np.asarray(m, dtype=np.float32).reshape(-1))
+    from raytracer_amd import renderer as Rm
+    for k, m in enumerate(scene["materials"]):
+        got, cutoff, flags = loaded.material(k)
+        want = Rm.gpu_material(m)
+        assert bytes(got)[:264] == bytes(want)[:264], k
+        assert cutoff == 0.5 and flags == 0
+    for k, c in enumerate(scene["cameras"]):
+        got = loaded.camera(k)
+        assert np.array_equal(got["transform"], np.asarray(c["transform"], np.float32).reshape(-1))
+        for key in ("verticalFov", "aspectRatio", "nearPlane", "aperture", "focusDistance"):
+            assert np.float32(got[key]) == np.float32(c[key]), key
+        assert got["farPlane"] == float("inf")
+    for k, l in enumerate(scene["lights"]):
+        got = loaded.light(k)
+        assert np.array_equal(got["transform"], np.asarray(l["transform"], np.float32).reshape(-1))
+        assert np.array_equal(got["color"], np.asarray(l["color"], np.float32)) and got["type"] == l["type"]
+        assert np.float32(got["intensity"]) == np.float32(l["intensity"])
+        assert np.float32(got["innerCone"]) == np.float32(l["innerCone"]) if l["type"] == 1 else True
+
+
+@pytest.mark.parametrize("container", ["gltf", "embedded", "glb"])
+def test_cornell_round_trip(R, tmp_path, container):
+    for light in ("point", "panel"):
+        scene = workloads.cornell_box(light=light)
+        path = write_scene(scene, tmp_path / f"cornell_{light}.{'glb' if container == 'glb' else 'gltf'}", container)
+        expect_same_scene(R.load_scene(path), scene)
+
+
+def test_textures_environment_and_material_extensions(R, tmp_path):
+    scene = workloads.textured_sky_scene()
+    rgbe = float_to_rgbe(np.asarray(scene["environment"]["pixels"], dtype=np.float32)[..., :3])
+    (tmp_path / "sky.hdr").write_bytes(encode_hdr(rgbe))
+    path = write_scene(scene, tmp_path / "sky.glb", "glb", environment_file="sky.hdr")
+    loaded = R.load_scene(path)
+    expect_same_scene(loaded, scene)
+    counts = loaded.counts()
+    assert counts["images"] == 1 and counts["textures"] == 1
+    image = loaded.image(0)
+    assert image["mimeType"] == 2 and image["encoded_bytes"] > 0
+    assert np.array_equal(image["rgba"], np.asarray(scene["images"][0], dtype=np.uint8))
+    assert loaded.texture(0) == dict(image=0, magFilter=0, minFilter=0, wrapU=10497, wrapV=10497)
+    env = loaded.environment()
+    assert (env["width"], env["height"]) == (rgbe.shape[1], rgbe.shape[0])
+    assert np.float32(env["rotation"]) == np.float32(0.4) and np.float32(env["strength"]) == np.float32(1.2)
+    assert np.float32(env["exposure"]) == np.float32(-0.5)
+    assert np.array_equal(env["pixels"], rgbe_to_float(rgbe))
+
+
+def test_node_hierarchy_trs_quantized_and_generated_indices(R, tmp_path):
+    """Children inherit their parents' transforms (T * R * S, depth first, in node order), normalised
+    integer attributes decode by the KHR_mesh_quantization rules, and a primitive without indices gets
+    0, 1, 2, ...; the default material is index 0 and glTF material i becomes i + 1."""
+    positions = np.array([[0, 0, 0], [127, 0, 0], [0, 127, 0], [0, 0, 127], [127, 127, 0], [0, 127, 127]], dtype=np.int8)
+    normals = np.array([[0, 0, 32767], [0, 0, -32767], [32767, 0, 0], [0, 0, -32768], [0, 32767, 0], [0, 0, 32767]],
+                       dtype=np.int16)
+    uvs = np.array([[0, 0], [65535, 0], [0, 65535], [255, 255], [1, 2], [3, 4]], dtype=np.uint16)
+    blob = bytearray()
+    blob += positions.tobytes() + b"\0" * 2      # 18 bytes + pad -> 20
+    blob += normals.tobytes()                     # 36 bytes at 20
+    blob += uvs.tobytes()                         # 24 bytes at 56
+    doc = {
+        "asset": {"version": "2.0"}, "extensionsUsed": ["KHR_mesh_quantization"],
+        "extensionsRequired": ["KHR_mesh_quantization"],
+        "buffers": [{"byteLength": len(blob)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 18, "byteStride": 3},
+                        {"buffer": 0, "byteOffset": 20, "byteLength": 36, "byteStride": 6},
+                        {"buffer": 0, "byteOffset": 56, "byteLength": 24}],
+        "accessors": [{"bufferView": 0, "componentType": 5120, "count": 6, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5122, "normalized": True, "count": 6, "type": "VEC3"},
+                      {"bufferView": 2, "componentType": 5123, "normalized": True, "count": 6, "type": "VEC2"}],
+        "materials": [{"name": "glass \\u00e9", "alphaMode": "MASK", "alphaCutoff": 0.25, "doubleSided": True,
+                       "extensions": {"KHR_materials_unlit": {}}}],
+        "meshes": [{"name": "tri", "primitives": [
+            {"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "material": 0},
+            {"attributes": {"POSITION": 0}}]}],
+        "cameras": [{"type": "perspective", "perspective": {"yfov": 0.5, "znear": 0.1, "zfar": 50.0, "aspectRatio": 1.5}}],
+        "nodes": [
+            {"name": "root", "translation": [1, 2, 3], "children": [1, 2]},
+            {"name": "arm", "rotation": [0, 0.7071067811865476, 0, 0.7071067811865476], "scale": [2, 2, 2], "mesh": 0,
+             "children": [3]},
+            {"name": "eye", "camera": 0, "translation": [0, 0, 5]},
+            {"name": "hand", "translation": [1, 0, 0], "mesh": 0},
+            {"name": "unused", "mesh": 0}],
+        "scenes": [{"nodes": [0]}],
+    }
+    text = json.dumps(doc).encode()
+    text += b" " * (-len(text) % 4)
+    while len(blob) % 4:
+        blob.append(0)
+    glb = (b"glTF" + struct.pack("<II", 2, 12 + 8 + len(text) + 8 + len(blob)) + struct.pack("<II", len(text), 0x4e4f534a) +
+           text + struct.pack("<II", len(blob), 0x004e4942) + bytes(blob))
+    path = tmp_path / "tree.glb"
+    path.write_bytes(glb)
+    loaded = R.load_scene(path)
+    counts = loaded.counts()
+    assert counts["geometries"] == 2 and counts["instances"] == 4 and counts["materials"] == 2 and counts["cameras"] == 1
+    first, second = loaded.geometry(0), loaded.geometry(1)
+    assert first["name"] == "tri.0" and second["name"] == "tri.1"
+    assert first["material"] == 1 and second["material"] == 0
+    assert np.array_equal(first["vertices"][:, 0:3], positions.astype(np.float32))
+    want_normals = np.maximum(normals.astype(np.float32) / np.float32(32767.0), np.float32(-1.0))
+    assert np.array_equal(first["vertices"][:, 3:6], want_normals)
+    assert np.array_equal(first["vertices"][:, 10:12], uvs.astype(np.float32) / np.float32(65535.0))
+    assert np.array_equal(second["indices"].reshape(-1), np.arange(6, dtype=np.uint32))
+    material, cutoff, flags = loaded.material(1)
+    assert np.float32(cutoff) == np.float32(0.25) and flags == (1 | 2 | 4)  # double sided, unlit, alpha mask
+    # depth first in node order: arm (2 primitives), then hand under it (2 primitives); "unused" is not in the scene
+    root = np.eye(4, dtype=np.float32)
+    root[:3, 3] = [1, 2, 3]
+    s = np.float32(0.7071067811865476)
+    x, y, z, w = np.float32(0), s, np.float32(0), s
+    rot = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 0],
+                    [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w), 0],
+                    [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y), 0], [0, 0, 0, 1]], dtype=np.float32)
+    arm_local = rot.copy()
+    arm_local[:3, :3] *= np.float32(2)
+    arm = root @ arm_local
+    hand_local = np.eye(4, dtype=np.float32)
+    hand_local[0, 3] = 1
+    hand = arm @ hand_local
+    got = [loaded.instance(k) for k in range(4)]
+    assert [g for g, _ in got] == [0, 1, 0, 1]
+    for (_, m), want in zip(got, (arm, arm, hand, hand)):
+        assert np.allclose(m.reshape(4, 4).T, want, rtol=0, atol=1e-6)
+    camera = loaded.camera(0)
+    assert np.allclose(camera["transform"].reshape(4, 4).T[:3, 3], [1, 2, 8])
+    assert camera["farPlane"] == 50.0 and np.float32(camera["aspectRatio"]) == np.float32(1.5)
+    assert camera["aperture"] == 0.0 and camera["focusDistance"] == 10.0  # the extras' defaults
+
+
+def test_light_units_and_scene_extras(R, tmp_path):
+    """Punctual intensities are divided by the luminous efficacy (683 unless the scene overrides it)."""
+    scene = workloads.cornell_box()
+    path = write_scene(scene, tmp_path / "a.gltf", "gltf", extras={"raytracer_luminous_efficacy": 0.0})
+    got = R.load_scene(path).light(0)
+    assert np.float32(got["intensity"]) == np.float32(np.float32(scene["lights"][0]["intensity"]) / np.float32(683.0))
+    assert got["range"] == float("inf") and np.float32(got["outerCone"]) == np.float32(0.7853982)
+
+
+def test_error_messages(R, tmp_path):
+    def load(doc, name="bad.gltf"):
+        path = tmp_path / name
+        path.write_text(json.dumps(doc) if isinstance(doc, dict) else doc)
+        return R.load_scene(path)
+
+    base = {"asset": {"version": "2.0"}}
+    with pytest.raises(engine.EngineError, match="Expected a glTF 2.0 .gltf or .glb scene"):
+        R.load_scene(tmp_path / "scene.obj")
+    with pytest.raises(engine.EngineError, match="glTF contains no scene"):
+        load(base)
+    with pytest.raises(engine.EngineError, match="Only triangle primitives are supported: lines"):
+        load(dict(base, scenes=[{}], meshes=[{"name": "lines", "primitives": [{"mode": 1, "attributes": {}}]}]))
+    with pytest.raises(engine.EngineError, match="Malformed mesh primitive"):
+        load(dict(base, scenes=[{}], meshes=[{"primitives": [{"attributes": {"NORMAL": 0}}]}]))
+    with pytest.raises(engine.EngineError, match="Orthographic cameras are not supported: ortho"):
+        load(dict(base, scenes=[{"nodes": [0]}], nodes=[{"camera": 0}],
+                  cameras=[{"name": "ortho", "type": "orthographic", "orthographic": {}}]))
+    with pytest.raises(engine.EngineError, match="Required glTF extension is not supported: KHR_draco"):
+        load(dict(base, scenes=[{}], extensionsRequired=["KHR_draco_mesh_compression"]))
+    with pytest.raises(engine.EngineError, match="Invalid glTF JSON"):
+        load('{"asset": {"version": "2.0"}, }')
+    blob = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32).tobytes() + np.array([0, 1, 5], np.uint16).tobytes()
+    import base64
+    doc = dict(base, scenes=[{}], buffers=[{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," +
+                                            base64.b64encode(blob).decode()}],
+               bufferViews=[{"buffer": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+               accessors=[{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                          {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+               meshes=[{"name": "m", "primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}])
+    with pytest.raises(engine.EngineError, match="Invalid triangle indices: m.0"):
+        load(doc)
+
+
+def png_reference(data):
+    """Independent PNG decode in numpy (8-bit, non-interlaced, colour types 0 / 2 / 6) for the comparison."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, header = 8, b"", None
+    while at < len(data):
+        length, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + length]
+        if kind == b"IHDR":
+            header = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + length
+    w, h, depth, colour, _, _, interlace = header
+    assert depth == 8 and interlace == 0 and colour in (0, 2, 6)
+    channels = {0: 1, 2: 3, 6: 4}[colour]
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * channels)
+    out = np.zeros((h, w * channels), dtype=np.int32)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        up = out[y - 1] if y else np.zeros(w * channels, dtype=np.int32)
+        for x in range(w * channels):
+            a = out[y, x - channels] if x >= channels else 0
+            b = up[x]
+            c = up[x - channels] if x >= channels else 0
+            if f == 0:
+                pred = 0
+            elif f == 1:
+                pred = a
+            elif f == 2:
+                pred = b
+            elif f == 3:
+                pred = (a + b) // 2
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+            out[y, x] = (line[x] + pred) & 255
+    px = out.reshape(h, w, channels).astype(np.uint8)
+    rgba = np.full((h, w, 4), 255, dtype=np.uint8)
+    if channels == 1:
+        rgba[..., :3] = px
+    else:
+        rgba[..., :channels] = px
+    return rgba
+
+
+def test_png_reader(R):
+    rng = np.random.default_rng(3)
+    image = rng.integers(0, 256, (37, 23, 4), dtype=np.uint8)
+    image[5:20, 3:17] = image[5, 3]  # flat region: long runs for the row filters
+    for colour in (6, 2, 0):
+        want = image.copy()
+        if colour != 6:
+            want[..., 3] = 255
+        if colour == 0:
+            want[..., 1] = want[..., 2] = want[..., 0]
+        data = encode_png(image, colour)
+        assert np.array_equal(png_reference(data), want)
+        assert np.array_equal(R.decode_png(data), want)
+    with pytest.raises(engine.EngineError):
+        R.decode_png(b"not a png at all")
+    truncated = encode_png(image)[:200]
+    with pytest.raises(engine.EngineError):
+        R.decode_png(truncated)
+
+
+def test_hdr_reader(R):
+    rng = np.random.default_rng(4)
+    pixels = (rng.random((19, 40, 3)) ** 4 * 50.0).astype(np.float32)
+    pixels[3:9, 5:30] = [2.0, 0.5, 0.25]  # runs
+    pixels[0, 0] = 0.0
+    rgbe = float_to_rgbe(pixels)
+    want = rgbe_to_float(rgbe)
+    # the format keeps 8 mantissa bits of the largest channel (truncated)
+    assert (np.abs(want[..., :3] - pixels) <= pixels.max(axis=2, keepdims=True) / 128.0 + 1e-6).all()
+    for rle in (True, False):
+        assert np.array_equal(R.decode_hdr(encode_hdr(rgbe, rle=rle)), want)
+    narrow = float_to_rgbe(pixels[:, :5])  # rows under 8 pixels are never run-length encoded
+    assert np.array_equal(R.decode_hdr(encode_hdr(narrow)), rgbe_to_float(narrow))
+    with pytest.raises(engine.EngineError):
+        R.decode_hdr(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 1 +X 1\n\0\0\0\0")
+
+
+ASSETS = "/root/reference/assets"
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="the reference's asset files are not on this machine")
+def test_readers_on_the_reference_assets(R):
+    """The image files the reference ships (inputs only; nothing of them is copied into the repository)."""
+    for name in ("checker_blue.png", "checker_green.png", "checker_red.png"):
+        data = open(os.path.join(ASSETS, "textures", name), "rb").read()
+        got = R.decode_png(data)
+        assert got.shape == (512, 512, 4)
+        header = struct.unpack(">IIBBBBB", data[16:29])
+        if header[2] == 8 and header[3] in (0, 2, 6) and header[6] == 0:
+            small = png_reference(data)[:16]
+            assert np.array_equal(got[:16], small)
+    for name, shape in (("rtiow_sky.hdr", (512, 1024)),):
+        data = open(os.path.join(ASSETS, "hdri", name), "rb").read()
+        got = R.decode_hdr(data)
+        assert got.shape[:2] == shape and np.isfinite(got).all() and (got[..., 3] == 1.0).all() and got[..., :3].max() > 1.0
