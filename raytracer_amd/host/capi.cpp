@@ -1,6 +1,7 @@
 // C binding of the host layer (rt::Scene + rt::Renderer) for callers that cannot
 // use the C++ classes directly: the Python mirror, the tests and the benchmark.
 // Exceptions become a non-zero return and a message (rth_last_error()).
+#include "image.hpp"
 #include "renderer.hpp"
 
 #include "rt_types.h"
@@ -325,6 +326,14 @@ int rth_decode_hdr(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t*
         if (out)
             std::memcpy(out, pixels.data(), pixels.size() * sizeof(rt::Vec4));
     });
+}
+
+// The image writers of the command-line renderer (row 0 = bottom row, as the renderer hands pixels out).
+int rth_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba) {
+    return guarded([&] { rt::writePng(path, width, height, {rgba, static_cast<size_t>(width) * height * 4}); });
+}
+int rth_write_exr(const char* path, uint32_t width, uint32_t height, const float* rgba) {
+    return guarded([&] { rt::writeExr(path, width, height, {rgba, static_cast<size_t>(width) * height * 4}); });
 }
 
 rt::Renderer* rth_renderer_create(const rt::Scene* scene, uint32_t width, uint32_t height, int finalProfile) {

@@ -96,6 +96,8 @@ _SIG = {
     "rth_scene_get_environment": (C.c_int, [_vp, _vp, _vp]),
     "rth_decode_png": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
     "rth_decode_hdr": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
+    "rth_write_png": (C.c_int, [C.c_char_p, _u32, _u32, _vp]),
+    "rth_write_exr": (C.c_int, [C.c_char_p, _u32, _u32, _vp]),
     "rth_renderer_create": (_vp, [_vp, _u32, _u32, C.c_int]),
     "rth_renderer_destroy": (None, [_vp]),
     "rth_renderer_render": (C.c_int, [_vp, _vp]),
@@ -317,6 +319,21 @@ def decode_hdr(data):
     out = np.empty((h.value, w.value, 4), dtype=np.float32)
     _check(lib.rth_decode_hdr(_p(buf), buf.size, C.byref(w), C.byref(h), _p(out)))
     return out
+
+
+def write_png(path, rgba):
+    """rt::writePng: (height, width, 4) uint8, row 0 = bottom row."""
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    _check(load().rth_write_png(os.fsencode(str(path)), a.shape[1], a.shape[0], _p(a)))
+
+
+def write_exr(path, rgba):
+    """rt::writeExr: (height, width, 4) float32, row 0 = bottom row."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    _check(load().rth_write_exr(os.fsencode(str(path)), a.shape[1], a.shape[0], _p(a)))
+
+
+CLI_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer")
 
 
 class Renderer:

@@ -229,3 +229,30 @@ def test_scene_loaded_from_gltf_renders_the_same(R, tmp_path):
     b.render()
     assert np.array_equal(a.linear_pixels(), b.linear_pixels())
     assert a.linear_pixels()[..., :3].max() > 0.0
+
+
+def test_command_line_renderer_writes_the_renderer_s_image(R, tmp_path):
+    """raytracer scene.glb --output x.png / x.exr: the files hold what Renderer::pixels() /
+    linearPixels() return for the same scene, size, profile and sample count (rows flipped top-down)."""
+    import subprocess
+    from gltf_writer import write_scene
+    from test_scene_loader import png_reference, read_exr
+    scene = workloads.cornell_box(light="panel")
+    path = write_scene(scene, tmp_path / "cornell.glb", "glb")
+    w, h, spp = 80, 48, 3
+    for name in ("out.png", "out.exr"):
+        p = subprocess.run([R.CLI_PATH, str(path), "--profile", "preview", "--width", str(w), "--height", str(h),
+                            "--samples", str(spp), "--denoise", "off", "--output", str(tmp_path / name)],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        assert "1 cameras, 0 lights" in p.stdout and f"Done at {spp} spp" in p.stdout and "Mrays/s" in p.stdout
+    r = R.Renderer(R.load_scene(path), w, h, 0)
+    for _ in range(spp):
+        r.render()
+    assert np.array_equal(png_reference((tmp_path / "out.png").read_bytes()), r.pixels().reshape(h, w, 4)[::-1])
+    with np.errstate(over="ignore"):
+        want = r.linear_pixels().reshape(h, w, 4)[::-1].astype(np.float16).astype(np.float32)
+    assert np.array_equal(read_exr(tmp_path / "out.exr"), want)
+    p = subprocess.run([R.CLI_PATH, str(path), "--output", str(tmp_path / "x.png"), "--denoise", "on"],
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "denoiser is not part of this build" in p.stderr

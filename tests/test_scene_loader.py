@@ -315,3 +315,85 @@ def test_readers_on_the_reference_assets(R):
         data = open(os.path.join(ASSETS, "hdri", name), "rb").read()
         got = R.decode_hdr(data)
         assert got.shape[:2] == shape and np.isfinite(got).all() and (got[..., 3] == 1.0).all() and got[..., :3].max() > 1.0
+
+
+def read_exr(path):
+    """Minimal reader for the scan-line, uncompressed, half-float files rt::writeExr produces."""
+    data = open(path, "rb").read()
+    assert struct.unpack("<II", data[:8]) == (20000630, 2)
+    at, channels, window = 8, [], None
+    while data[at] != 0:
+        end = data.index(b"\0", at)
+        name = data[at:end].decode()
+        at = end + 1
+        end = data.index(b"\0", at)
+        kind = data[at:end].decode()
+        at = end + 1
+        size, = struct.unpack("<I", data[at:at + 4])
+        body = data[at + 4:at + 4 + size]
+        at += 4 + size
+        if name == "channels":
+            p = 0
+            while body[p] != 0:
+                e = body.index(b"\0", p)
+                channels.append((body[p:e].decode(), struct.unpack("<I", body[e + 1:e + 5])[0]))
+                p = e + 1 + 16
+        elif name == "dataWindow":
+            window = struct.unpack("<4i", body)
+        elif name == "compression":
+            assert body == b"\0" and kind == "compression"
+        elif name == "lineOrder":
+            assert body == b"\0"
+    at += 1
+    assert channels == [("A", 1), ("B", 1), ("G", 1), ("R", 1)]
+    w, h = window[2] + 1, window[3] + 1
+    offsets = struct.unpack(f"<{h}Q", data[at:at + 8 * h])
+    image = np.zeros((h, w, 4), dtype=np.float32)
+    for y in range(h):
+        row, size = struct.unpack("<iI", data[offsets[y]:offsets[y] + 8])
+        assert row == y and size == w * 8
+        line = np.frombuffer(data, dtype=np.float16, count=4 * w, offset=offsets[y] + 8).reshape(4, w).astype(np.float32)
+        image[y, :, 3], image[y, :, 2], image[y, :, 1], image[y, :, 0] = line[0], line[1], line[2], line[3]
+    return image
+
+
+def test_image_writers(R, tmp_path):
+    """writePng / writeExr flip the renderer's bottom-up rows; PNG is lossless, EXR rounds to binary16."""
+    rng = np.random.default_rng(8)
+    rgba = rng.integers(0, 256, (13, 21, 4), dtype=np.uint8)
+    R.write_png(tmp_path / "a.png", rgba)
+    data = (tmp_path / "a.png").read_bytes()
+    assert np.array_equal(png_reference(data), rgba[::-1])
+    assert np.array_equal(R.decode_png(data), rgba[::-1])
+    linear = (rng.random((13, 21, 4)) ** 3 * 40.0).astype(np.float32)
+    linear[0, 0] = [0.0, 1e-9, 70000.0, 1.0]   # zero, underflow, overflow to infinity
+    linear[0, 1] = [6.1e-5, 3e-6, 65504.0, -2.5]  # smallest normal, a subnormal, largest finite, negative
+    R.write_exr(tmp_path / "a.exr", linear)
+    with np.errstate(over="ignore"):
+        want = linear[::-1].astype(np.float16).astype(np.float32)  # numpy rounds to nearest even as well
+    assert np.array_equal(read_exr(tmp_path / "a.exr"), want)
+    with pytest.raises(engine.EngineError, match="Unable to write PNG"):
+        R.write_png(tmp_path / "missing" / "a.png", rgba)
+
+
+def test_command_line_options(R):
+    """Option handling of the command-line renderer, as far as it goes without a GPU."""
+    import subprocess
+    if not os.path.exists(R.CLI_PATH):
+        pytest.skip("the raytracer executable is not built")
+
+    def run(*args):
+        p = subprocess.run([R.CLI_PATH, *args], capture_output=True, text=True, timeout=60)
+        return p.returncode, p.stdout, p.stderr
+
+    code, _, err = run()
+    assert code == 1 and err.startswith("error: usage: raytracer <scene.gltf|scene.glb>")
+    assert run("x.glb", "--samples")[2] == "error: Missing option value\n"
+    assert run("x.glb", "--samples", "0")[2] == "error: Invalid sample count\n"
+    assert run("x.glb", "--width", "12a")[2] == "error: Invalid width\n"
+    assert run("x.glb", "--profile", "draft")[2] == "error: Expected preview or final profile\n"
+    assert run("x.glb", "--denoise", "maybe")[2] == "error: Expected on or off for denoise\n"
+    assert run("x.glb", "--fast", "1")[2] == "error: Unknown option: --fast\n"
+    assert run("x.glb", "--output", "a.jpg")[2] == "error: Output must use .png or .exr\n"
+    assert "no interactive viewer" in run("x.glb")[2]
+    assert "Expected a glTF 2.0 .gltf or .glb scene" in run("x.obj", "--output", "a.png")[2]
