@@ -283,7 +283,7 @@ def main():
     if photon is not None:
         out["photon_gathers_per_s"] = photon["gathers_per_s"]
         out["photon"] = photon
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(scene, args, args.width, args.height, profile)
     print(json.dumps(out))
     if world > 1:
