@@ -193,27 +193,43 @@ __global__ __launch_bounds__(256) void leafBoundsKernel(const Box4* boxes, const
         bounds[(n - 1U) + k] = boxes[order[k]];
 }
 
-// Bottom-up: the second thread to reach a node merges its children.  The
-// fences order each thread's box stores before its arrival count and the
-// sibling's box loads after it, across CUs and XCDs.
-__global__ __launch_bounds__(256) void refitKernel(const uint32_t* left, const uint32_t* right,
-                                                   const uint32_t* parent, uint32_t n, Box4* bounds,
-                                                   uint32_t* arrivals) {
+// Bottom-up bounds, one launch per wave of ready nodes.  A node is ready when
+// both children have their boxes; the second child to report at the parent's
+// arrival counter puts the parent on the next launch's list.  Boxes written by
+// one launch are read by the next, so the kernel boundary is the only ordering
+// needed (no fences, whose agent-scope form writes back a whole L2 on this
+// part: the single-launch version with fences took 5.4 ms for 871 k triangles).
+// Which thread appends a node varies from run to run, the boxes do not.
+//
+// level 0 lists the parents both of whose children are leaves; counts[k] is the
+// length of list k and is zeroed before the first launch.
+__global__ __launch_bounds__(256) void refitLeavesKernel(const uint32_t* parent, uint32_t n, uint32_t* arrivals,
+                                                         uint32_t* list, uint32_t* counts) {
     const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= n || n < 2)
         return;
-    uint32_t node = parent[(n - 1U) + k];
-    while (node != kNoHit) {
-        __threadfence();
-        if (atomicAdd(&arrivals[node], 1U) == 0U)
-            return;
-        __threadfence();
-        const Box4 a = bounds[left[node]];
-        const Box4 b = bounds[right[node]];
-        bounds[node] = merge(a, b);
-        node = parent[node];
+    const uint32_t node = parent[(n - 1U) + k];
+    if (atomicAdd(&arrivals[node], 1U) == 1U)
+        list[atomicAdd(&counts[0], 1U)] = node;
+}
+
+__global__ __launch_bounds__(256) void refitLevelKernel(const uint32_t* left, const uint32_t* right,
+                                                        const uint32_t* parent, Box4* bounds, uint32_t* arrivals,
+                                                        const uint32_t* listIn, uint32_t* listOut, uint32_t* counts,
+                                                        uint32_t level) {
+    const uint32_t ready = counts[level];
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < ready;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const uint32_t node = listIn[i];
+        bounds[node] = merge(bounds[left[node]], bounds[right[node]]);
+        const uint32_t up = parent[node];
+        if (up != kNoHit && atomicAdd(&arrivals[up], 1U) == 1U)
+            listOut[atomicAdd(&counts[level + 1U], 1U)] = up;
     }
 }
+
+constexpr uint32_t kRefitMaxLevels = 256;  // far above any radix-tree height (64 key bits + 32 index bits)
+constexpr uint32_t kRefitBatch = 16;       // launches between looks at the list length
 
 // ---- 3b. agglomerative binary tree (parallel locally-ordered clustering) ----
 //
@@ -692,9 +708,34 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         hipLaunchKernelGGL(radixTreeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, sortedKeys, n,
                            left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), first.as<uint32_t>(),
                            last.as<uint32_t>());
+        DeviceBuffer readyA, readyB, readyCounts;
+        RT_TRY(readyA.allocate(sizeof(uint32_t) * n));
+        RT_TRY(readyB.allocate(sizeof(uint32_t) * n));
+        RT_TRY(readyCounts.allocate(sizeof(uint32_t) * (kRefitMaxLevels + 1U)));
         RT_HIP(hipMemsetAsync(arrivals.data, 0, sizeof(uint32_t) * n, stream));
-        hipLaunchKernelGGL(refitKernel, dim3(blocks), dim3(256), 0, stream, left.as<uint32_t>(), right.as<uint32_t>(),
-                           parent.as<uint32_t>(), n, bounds.as<Box4>(), arrivals.as<uint32_t>());
+        RT_HIP(hipMemsetAsync(readyCounts.data, 0, sizeof(uint32_t) * (kRefitMaxLevels + 1U), stream));
+        hipLaunchKernelGGL(refitLeavesKernel, dim3(blocks), dim3(256), 0, stream, parent.as<uint32_t>(), n,
+                           arrivals.as<uint32_t>(), readyA.as<uint32_t>(), readyCounts.as<uint32_t>());
+        uint32_t* listIn = readyA.as<uint32_t>();
+        uint32_t* listOut = readyB.as<uint32_t>();
+        // a level holds at most half the nodes of the one below; the grid-stride loop covers any list
+        const unsigned levelBlocks = std::max(1U, std::min(blocks, 2048U));
+        bool finished = false;
+        for (uint32_t level = 0; level < kRefitMaxLevels && !finished; level += kRefitBatch) {
+            for (uint32_t k = level; k < level + kRefitBatch; ++k) {
+                hipLaunchKernelGGL(refitLevelKernel, dim3(levelBlocks), dim3(256), 0, stream, left.as<uint32_t>(),
+                                   right.as<uint32_t>(), parent.as<uint32_t>(), bounds.as<Box4>(),
+                                   arrivals.as<uint32_t>(), listIn, listOut, readyCounts.as<uint32_t>(), k);
+                std::swap(listIn, listOut);
+            }
+            uint32_t remaining = 0;
+            RT_HIP(hipMemcpyAsync(&remaining, readyCounts.as<uint32_t>() + level + kRefitBatch, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipStreamSynchronize(stream));
+            finished = remaining == 0;
+        }
+        if (!finished)
+            return failInvalid("bounds pass did not finish");
     }
     RT_HIP(hipGetLastError());
 
