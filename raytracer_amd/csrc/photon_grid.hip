@@ -1,5 +1,5 @@
 // Photon hash grid for gfx950: bucket keys, a stable radix sort of (key, index)
-// pairs, bucket offsets by binary search over the sorted keys, a payload
+// pairs, bucket offsets from the key boundaries of the sorted list, a payload
 // reorder staged through LDS, and the radius gather.
 //
 // Replaces src/photon_grid.cu:17-83 (count / scan / scatter with global
@@ -25,11 +25,26 @@ __global__ __launch_bounds__(256) void photonKeysKernel(const float* positions, 
     }
 }
 
-// offsets[b] = first sorted position whose key is >= b, for b in [0, bucketCount].
-// Neighbouring buckets search neighbouring key ranges, so a wave's probes share
-// cache lines.
+// offsets[b] = first sorted position whose key is >= b, for b in [0, bucketCount]:
+// position i starts every bucket in (key[i-1], key[i]], with key[-1] = -1 and
+// key[n] = bucketCount.  One streaming pass over the sorted keys; every entry
+// of offsets is written exactly once.
 __global__ __launch_bounds__(256) void photonOffsetsKernel(const uint32_t* sortedKeys, uint32_t n,
                                                            uint32_t bucketCount, uint32_t* offsets) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i > n)
+        return;
+    const uint32_t first = i == 0 ? 0U : sortedKeys[i - 1U] + 1U;
+    const uint32_t last = i == n ? bucketCount : sortedKeys[i];
+    for (uint32_t bucket = first; bucket <= last; ++bucket)
+        offsets[bucket] = static_cast<uint32_t>(i);
+}
+
+// The same table by binary search, one thread per bucket: for sparse maps (far
+// fewer photons than buckets), where the boundary pass would leave long runs of
+// buckets to single threads.
+__global__ __launch_bounds__(256) void photonOffsetsSearchKernel(const uint32_t* sortedKeys, uint32_t n,
+                                                                 uint32_t bucketCount, uint32_t* offsets) {
     const size_t b = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b > bucketCount)
         return;
@@ -191,8 +206,12 @@ rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, ui
     int result = 0;
     const int bits = log2Exact(bucketCount) > 0 ? log2Exact(bucketCount) : 1;
     RT_TRY(radixSortPairs<uint32_t>(s.keys, s.idx, count, bits, s.table, s.partials, stream, &result));
-    hipLaunchKernelGGL(photonOffsetsKernel, dim3(divUp(static_cast<size_t>(bucketCount) + 1U, 256)), dim3(256), 0,
-                       stream, s.keys[result], count, bucketCount, offsets);
+    if (count >= bucketCount / 8U)
+        hipLaunchKernelGGL(photonOffsetsKernel, dim3(divUp(static_cast<size_t>(count) + 1U, 256)), dim3(256), 0, stream,
+                           s.keys[result], count, bucketCount, offsets);
+    else
+        hipLaunchKernelGGL(photonOffsetsSearchKernel, dim3(divUp(static_cast<size_t>(bucketCount) + 1U, 256)), dim3(256),
+                           0, stream, s.keys[result], count, bucketCount, offsets);
     hipLaunchKernelGGL(photonReorderKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, photons, s.idx[result],
                        count, sorted);
     RT_HIP(hipGetLastError());
