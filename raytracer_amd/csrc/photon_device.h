@@ -35,7 +35,8 @@ __device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float 
 // Flux sum of one query in the reference's own order (cells z, y, x from -1 to
 // 1, a bucket reached twice counted once, photons in stored order), so the
 // float sums match a scalar evaluation bit for bit.  `visitedPhotons`, when not
-// null, receives the number of photons read.
+// null, receives the number of photons read (cells out of the sphere's reach
+// are not read, see below).
 __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
                                   float radius, float hx, float hy, float hz, float nx, float ny, float nz, float& fx,
                                   float& fy, float& fz, uint32_t* visitedPhotons) {
@@ -55,17 +56,68 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
                                   static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
                                   static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
     }
+    // Cells the sphere cannot reach are not read: every photon in them fails the
+    // distance test, so leaving them out changes no sum.  gap[a][d] is a lower
+    // bound of the distance along axis a to the neighbour cell at offset d - 1,
+    // shortened by a tolerance that covers the rounding of the cell assignment
+    // (floor of an IEEE quotient) and of the products here; with coordinates too
+    // large for that reasoning nothing is skipped.
+    float gap[3][3];
+    bool mayCull = true;
+    {
+        const float h[3] = {hx, hy, hz};
+        const int cell[3] = {cx, cy, cz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float base = static_cast<float>(cell[a]);
+            const float tolerance = fmaxf(fabsf(h[a]), radius) * 0x1p-19f;
+            const float below = (h[a] - base * radius) - tolerance;           // to the cell at -1
+            const float above = ((base + 1.0f) * radius - h[a]) - tolerance;  // to the cell at +1
+            gap[a][0] = below > 0.0f ? below * below : 0.0f;
+            gap[a][1] = 0.0f;
+            gap[a][2] = above > 0.0f ? above * above : 0.0f;
+            mayCull = mayCull && fabsf(base) < 0x1p22f && radius > 0.0f;
+        }
+    }
+    const float reach = radiusSquared * (1.0f + 0x1p-16f);
+    // a bucket reached twice is read where the reference reads it: at its first
+    // cell, even when that cell is out of reach and a later one is not
+    uint32_t skip = 0, repeatedLater = 0;
 #pragma unroll
     for (int c = 0; c < 27; ++c) {
-        bool seen = false;
 #pragma unroll
         for (int p = 0; p < c; ++p)
-            seen |= visited[p] == visited[c];
-        if (seen)
+            if (visited[p] == visited[c]) {
+                skip |= 1U << c;
+                repeatedLater |= 1U << p;
+            }
+        // keeps the 351 comparisons in program order: left to itself the
+        // scheduler evaluates them as one wide tree and runs out of registers
+        asm volatile("" : "+v"(skip), "+v"(repeatedLater));
+    }
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        const int dx = c % 3, dy = (c / 3) % 3, dz = c / 9;
+        const bool outOfReach = mayCull && gap[0][dx] + gap[1][dy] + gap[2][dz] > reach;
+        if (outOfReach && !(repeatedLater >> c & 1U))
+            skip |= 1U << c;
+    }
+    // the walk itself is a plain loop (the bucket of cell c is hashed again
+    // rather than kept): unrolled 27 times the compiler hoists all the range
+    // loads and the kernel's register use quadruples
+#pragma unroll 1
+    for (int c = 0; c < 27; ++c) {
+        if (skip >> c & 1U)
             continue;
-        const uint32_t begin = cellStart[visited[c]];
-        const uint32_t end = cellStart[visited[c] + 1U];
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const uint32_t bucket =
+            bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
+                         static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
+                         static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+        const uint32_t begin = cellStart[bucket];
+        const uint32_t end = cellStart[bucket + 1U];
         read += end - begin;
+#pragma unroll 2
         for (uint32_t index = begin; index < end; ++index) {
             const float* p = reinterpret_cast<const float*>(sorted + index);
             const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
