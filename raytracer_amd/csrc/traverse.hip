@@ -112,6 +112,19 @@ using namespace rt;
 
 extern "C" {
 
+#ifdef RT_TRACE_PROFILE
+// Development aid: launch timeline of the batched queries (see gTraceClock); reset arms the min / max slots.
+rt_status rt_trace_clock(unsigned long long* out8, int reset) {
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gTraceClock), sizeof(unsigned long long) * 8));
+    if (reset) {
+        const unsigned long long init[8] = {~0ULL, ~0ULL, 0, 0, 0, 0, 0, 0};
+        RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gTraceClock), init, sizeof(init)));
+    }
+    return RT_SUCCESS;
+}
+#endif
+
 rt_status rt_trace_closest(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax,
                            uint32_t n, rt_ray_hit* hits, uint32_t* instance, void* stream) {
     RT_TRY(checkScene(scene));

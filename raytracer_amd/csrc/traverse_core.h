@@ -187,6 +187,9 @@ constexpr uint32_t kDone = 0xffffffffU;  // "no more work" reference (has the le
 #ifdef RT_TRACE_PROFILE
 static __device__ float gTraceProfile[64];  // one copy per translation unit
 static __device__ unsigned int gTraceHistogram[64];  // per kernel: rays by log2(steps), 16 bins
+// launch timeline in 100 MHz ticks: [0] earliest wave start, [1] earliest sight of an empty feed,
+// [2] latest wave end; [3] wave turns after the feed emptied, [4] lanes active in them
+static __device__ unsigned long long gTraceClock[8];
 #define RT_SITE(k)                                                             \
     do {                                                                       \
         if ((k) == 0 || (k) == 3)                                              \
@@ -586,10 +589,22 @@ template <bool COUNT, typename Fetch, typename Store>
 __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Fetch&& fetch, Store&& store) {
     bool active = false;
     uint32_t rayIndex = 0;
-#ifdef RT_TRACE_STEP_CAP
-    int turns = 0;
+#ifdef RT_TRACE_PROFILE
+    bool sawDrained = false;
+    unsigned long long drainTurns = 0, drainLanes = 0;
+    if ((threadIdx.x & 63) == 0)
+        atomicMin(&gTraceClock[0], wall_clock64());
 #endif
     for (;;) {
+#ifdef RT_TRACE_PROFILE
+        if (feed.drained()) {
+            if (!sawDrained && (threadIdx.x & 63) == 0)
+                atomicMin(&gTraceClock[1], wall_clock64());
+            sawDrained = true;
+            ++drainTurns;
+            drainLanes += __popcll(__ballot(active));
+        }
+#endif
         const unsigned long long idleMask = __ballot(!active);
         if (!feed.drained() && __popcll(idleMask) >= RT_TRACE_REFILL) {
             uint32_t index = 0;
@@ -625,14 +640,7 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
                 }
             }
         }
-#ifdef RT_TRACE_STEP_CAP  // experiment only: rays give up after this many turns
-        if (active && ++turns > RT_TRACE_STEP_CAP)
-            walk.node = kDone;
-#endif
         if (active && walk.node == kDone) {
-#ifdef RT_TRACE_STEP_CAP
-            turns = 0;
-#endif
             store(rayIndex, walk.result());
             active = false;
 #ifdef RT_TRACE_PROFILE
@@ -642,6 +650,11 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
     }
 #ifdef RT_TRACE_PROFILE
     walk.flushProfile();
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&gTraceClock[2], wall_clock64());
+        atomicAdd(&gTraceClock[3], drainTurns);
+        atomicAdd(&gTraceClock[4], drainLanes);
+    }
 #endif
 }
 
