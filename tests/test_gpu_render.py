@@ -55,6 +55,16 @@ def test_cornell_point_light_matches_oracle(R, oracle):
     assert stats["extend_rays"] >= 256 * 256 and stats["shadow_rays"] > 0 and stats["gather_queries"] == 0
 
 
+def test_ragged_frame_sizes_match_oracle(R, oracle):
+    """Widths that are not a multiple of 8 and pixel counts that are not a multiple of the workgroup size
+    (the tile numbering of paths falls back to row order; the last workgroups are partly empty)."""
+    scene = workloads.cornell_box()
+    for w, h in ((50, 37), (72, 13), (1, 1)):
+        r, host, gpu, cpu = render_both(R, oracle, scene, w, h, 1)
+        assert close_fraction(gpu, cpu) > 0.99, (w, h)
+        assert (gpu[:, 3] == 1.0).all()
+
+
 def test_cornell_golden_image(R):
     """The committed oracle image of config 1 (Cornell, 1 spp, depth 5; 128 x 128 to keep the fixture small)."""
     import os

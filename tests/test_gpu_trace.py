@@ -119,6 +119,41 @@ def test_dragon_standin_primary_and_bounce_rays(engine, oracle):
     check_scene(engine, oracle, scene, (np.concatenate([o1, o2]), np.concatenate([d1, d2])))
 
 
+def test_full_frame_properties_without_the_oracle(engine):
+    """The benchmark's size (one ray per pixel of a 1080p frame plus as many incoherent rays, 871 k
+    triangles), checked through properties that need no CPU answer: the same call twice gives the same
+    bits; a ray's result does not depend on where it sits in the batch (rays are handed to persistent
+    waves in whatever order they ask); any-hit agrees with closest-hit; the hit interval is (tmin, tmax]."""
+    import torch
+    scene = workloads.dragon_cornell()
+    top, blases = engine_scene(engine, scene)
+    o1, d1 = workloads.camera_rays(scene, 1920, 1080)
+    o2, d2 = workloads.random_rays(scene, len(o1), seed=8)
+    o, d = dev(np.concatenate([o1, o2])), dev(np.concatenate([d1, d2]))
+    hits, inst = top.trace_closest(o, d)
+    again, inst2 = top.trace_closest(o, d)
+    assert torch.equal(hits.view(torch.int32), again.view(torch.int32)) and torch.equal(inst, inst2)
+    order = torch.randperm(o.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    shuffled, sinst = top.trace_closest(o[order].contiguous(), d[order].contiguous())
+    assert torch.equal(shuffled.view(torch.int32), hits[order].view(torch.int32)) and torch.equal(sinst, inst[order])
+    found = hits[:, 3].view(torch.int32) != -1
+    assert 0.5 < float(found.float().mean()) <= 1.0
+    assert torch.equal(top.trace_any(o, d).bool(), found)
+    # tmax = t keeps the hit (closed end); the next float below t loses it or finds nothing nearer or equal
+    t = hits[:, 0]
+    closed = d.clone()
+    closed[found, 3] = t[found]
+    same, _ = top.trace_closest(o, closed)
+    assert torch.equal(same[found].view(torch.int32), hits[found].view(torch.int32))
+    opened = d.clone()
+    opened[found, 3] = torch.nextafter(t[found], torch.zeros_like(t[found]))
+    before, _ = top.trace_closest(o, opened)
+    missed = before[found][:, 3].view(torch.int32) == -1
+    assert bool((missed | (before[found][:, 0] < t[found])).all())
+    s = top.stats()
+    assert s.triangleCount == 871212 and s.instanceCount == len(scene["instances"])
+
+
 def test_counters_and_empty_launch(engine, oracle):
     import torch
     scene = workloads.cornell_box()
