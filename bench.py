@@ -108,6 +108,22 @@ def photon_benchmark(eng, workloads, args, rank, steps):
     }
 
 
+def profiled_traffic():
+    """HBM bytes per trace launch from the newest committed rocprofv3 PMC summary (profiles/*_bench_summary.txt:
+    FETCH_SIZE x2-corrected plus WRITE_SIZE, separate --pmc passes of this same command), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_summary.txt"))):
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 6 and f[0].startswith("traceKernel<false>"):
+                try:
+                    best = (float(f[3]) * 1e6 + float(f[4]) * 1024.0, os.path.basename(path))  # fetch_x2_MB, WRITE_KiB
+                except ValueError:
+                    pass
+    return best
+
+
 def cpu_baseline(scene, args, width, height, profile):
     """The oracle's integrator (same frame, sample 0) on the host cores over a bounded band of pixel
     rows from the middle of the image, rays counted the way the GPU counts them."""
@@ -234,6 +250,7 @@ def main():
         return
 
     trace_ms, trace_launches = stages["trace"]
+    traffic = profiled_traffic() if args.workload == "dragon-cornell" and (args.width, args.height) == (1920, 1080) else None
     achieved = staged_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
     p = renderer.launch_params()
     out = {
@@ -272,7 +289,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic[0] if traffic else None,
+            "traffic_source": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {traffic[1]}"
+                               if traffic else None),
+            "algorithmic_bytes_per_launch": staged_rays * bytes_per_ray / max(trace_launches, 1),
             "bytes_per_ray": bytes_per_ray,
             "nodes_per_ray": nodes_per_ray,
             "triangles_per_ray": tris_per_ray,
