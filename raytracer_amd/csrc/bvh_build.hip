@@ -21,6 +21,11 @@
 #include <cstring>
 #include <vector>
 
+// Whether node slots left over by the collapse are spent on splitting leaves.
+#ifndef RT_BLAS_SPLIT_LEAVES
+#define RT_BLAS_SPLIT_LEAVES 1
+#endif
+
 namespace rt {
 namespace {
 
@@ -432,6 +437,29 @@ __device__ inline int gatherChildren(uint32_t root, uint32_t n, const uint32_t* 
         children[pick + 1] = makeChild(right[id], n, first, last, bounds);
         ++count;
     }
+#if RT_BLAS_SPLIT_LEAVES
+    // The traversal tests all eight slots of a node whether they are used or
+    // not, so slots left over are spent on splitting the leaves: each part
+    // gets a box of its own and a ray only meets the triangles whose box it hits.
+    while (count < kWide) {
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < count; ++k)
+            if (children[k].count > 1U && children[k].count <= static_cast<uint32_t>(kMaxLeaf) &&
+                children[k].area > best) {
+                best = children[k].area;
+                pick = k;
+            }
+        if (pick < 0)
+            break;
+        const uint32_t id = children[pick].id;
+        for (int k = count; k > pick + 1; --k)
+            children[k] = children[k - 1];
+        children[pick] = makeChild(left[id], n, first, last, bounds);
+        children[pick + 1] = makeChild(right[id], n, first, last, bounds);
+        ++count;
+    }
+#endif
     return count;
 }
 
@@ -1074,7 +1102,7 @@ rt_status rt_blas_build(const void* vertices, uint32_t vertexCount, uint32_t ver
         return failInvalid("empty geometry");
     if (vertexStride < 12 || vertexStride % 4 != 0)
         return failInvalid("vertex stride must be a multiple of 4 and at least 12");
-    if (triangleCount > (1U << 28) - 1U)
+    if (triangleCount > (1U << 28) - 2U)
         return failInvalid("too many triangles");
     auto* blas = new rt_blas();
     RT_HIP(hipGetDevice(&blas->device));

@@ -42,10 +42,17 @@ namespace rt {
 // Persistent launches: wide nodes a lane may walk per turn before its leaf, and
 // how many idle lanes make a wave fetch new rays.
 #ifndef RT_TRACE_NODE_STEPS
-#define RT_TRACE_NODE_STEPS 3
+#define RT_TRACE_NODE_STEPS 1
 #endif
 #ifndef RT_TRACE_REFILL
-#define RT_TRACE_REFILL 24
+#define RT_TRACE_REFILL 32
+#endif
+// Triangles a lane may test per turn, and whether a turn starts by reading the stack.
+#ifndef RT_TRACE_LEAF_STEPS
+#define RT_TRACE_LEAF_STEPS 2
+#endif
+#ifndef RT_TRACE_ORDER
+#define RT_TRACE_ORDER 0
 #endif
 // Workgroups launched per resident workgroup slot (1 = exactly one resident set).
 #ifndef RT_TRACE_GRID_SCALE
@@ -181,6 +188,9 @@ __device__ inline LdsUint ldsView(uint32_t* p) { return (LdsUint)p; }
 __device__ inline LdsFloat ldsView(float* p) { return (LdsFloat)p; }
 
 constexpr uint32_t kDone = 0xffffffffU;  // "no more work" reference (has the leaf bit set)
+// "take the next stack entry": has the leaf bit set and is no real leaf, whose
+// item index (bits 0-27) stays below 2^28 - 2
+constexpr uint32_t kPop = 0xfffffffeU;
 
 // Development aid (-DRT_TRACE_PROFILE): per code site, how many times a wave
 // issued it and with how many lanes, summed over every traversal kernel.
@@ -428,7 +438,7 @@ struct Traversal {
             return kLeafBit | (meta >> 5) << 28 | (n1.y + (meta & 31U));
         };
         if (hitMask == 0U) {
-            node = pop();
+            node = kPop;
             return;
         }
 #if RT_TRACE_SORTED_PUSH
@@ -532,7 +542,7 @@ struct Traversal {
         else if (count > 1U)
             node = kLeafBit | (count - 1U) << 28 | (first + 1U);
         else
-            node = pop();
+            node = kPop;
     }
 };
 
@@ -626,16 +636,28 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             uint32_t raySteps = 0;
             RT_SITE(5);
 #endif
-            // a burst: a few wide nodes, then at most one leaf
+            // a burst: a few wide nodes, then at most one leaf.  A step that
+            // runs out of work leaves kPop behind, and the stack is read at one
+            // place only, so that the lanes which need it go there together.
+#if RT_TRACE_ORDER == 1
+            if (walk.node == kPop)
+                walk.node = walk.pop();
+#endif
 #pragma unroll 1
-            for (int s = 0; s < RT_TRACE_NODE_STEPS && !(walk.node & kLeafBit); ++s)
-                walk.nodeStep();
-            if ((walk.node & kLeafBit) && walk.node != kDone) {
+            for (int s = 0; s < RT_TRACE_NODE_STEPS; ++s) {
+                if (!(walk.node & kLeafBit))
+                    walk.nodeStep();
+                if (walk.node == kPop)
+                    walk.node = walk.pop();
+                else if (walk.node & kLeafBit)
+                    break;
+            }
+            if ((walk.node & kLeafBit) && walk.node < kPop) {
                 if (!walk.inBottom) {
                     walk.enterInstance();
                 } else {
-                    const uint32_t count = (walk.node >> 28) & 7U;
-                    for (uint32_t k = 0; k < count && walk.node != kDone; ++k)
+                    const uint32_t count = min((walk.node >> 28) & 7U, static_cast<uint32_t>(RT_TRACE_LEAF_STEPS));
+                    for (uint32_t k = 0; k < count && walk.node < kPop; ++k)
                         walk.triangleStep();
                 }
             }
