@@ -31,13 +31,10 @@
 
 namespace rt {
 
-// Tuning knobs (compile-time): minimum waves per SIMD the register allocator must
-// leave room for, and whether children are pushed in distance order.
+// Tuning knob (compile-time): minimum waves per SIMD the register allocator must
+// leave room for.
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 5
-#endif
-#ifndef RT_TRACE_SORTED_PUSH
-#define RT_TRACE_SORTED_PUSH 1
 #endif
 // Persistent launches: wide nodes a lane may walk per turn before its leaf, and
 // how many idle lanes make a wave fetch new rays.
@@ -145,11 +142,6 @@ __device__ inline bool intersectTriangle(const Ray& r, const Shear& s, const uin
     u = V * rcp;
     v = W * rcp;
     return true;
-}
-
-__device__ inline uint32_t byteOf(uint32_t lo, uint32_t hi, int i) {
-    const unsigned long long both = static_cast<unsigned long long>(hi) << 32 | lo;
-    return static_cast<uint32_t>(both >> (8 * i)) & 0xffU;
 }
 
 // Workgroups that share an XCD (and its L2) get neighbouring ray ranges.
@@ -266,7 +258,7 @@ struct Traversal {
     float (&privateT)[kPrivateStack];
     TraceCounters counters;
     uint32_t topNodeLimit, instanceLimit;  // sizes of the top-level arrays
-    uint32_t nodeLimit, triangleLimit;     // sizes of the arrays of the instance the ray is in
+    uint32_t nodeLimit, itemLimit;         // sizes of the node and item arrays of the level the ray is in
     uint32_t violations;
 #ifdef RT_TRACE_PROFILE
     float profile[16] = {};
@@ -296,7 +288,7 @@ struct Traversal {
           idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), inBottom(false), found(false),
           anyHit(false), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
           bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
-          topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(0), triangleLimit(0), violations(0) {}
+          topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
 
     __device__ __forceinline__ void begin(const Ray& ray, float rayTmin, float rayTmax, uint32_t initInstance,
                                           uint32_t initPrimitive, bool stopAtFirstHit) {
@@ -309,6 +301,8 @@ struct Traversal {
         idz = __builtin_amdgcn_rcpf(cur.dz);
         nodes = topNodes;
         triangles = nullptr;
+        nodeLimit = topNodeLimit;
+        itemLimit = instanceLimit;
         instanceId = kNoHit;
         inBottom = false;
         found = false;
@@ -370,6 +364,8 @@ struct Traversal {
                 idy = __builtin_amdgcn_rcpf(cur.dy);
                 idz = __builtin_amdgcn_rcpf(cur.dz);
                 nodes = topNodes;
+                nodeLimit = topNodeLimit;
+                itemLimit = instanceLimit;
                 inBottom = false;
                 continue;
             }
@@ -383,7 +379,7 @@ struct Traversal {
     // and leave the others on the stack.
     __device__ __forceinline__ void nodeStep() {
         RT_SITE(0);
-        RT_GUARD(node < (inBottom ? nodeLimit : topNodeLimit));
+        RT_GUARD(node < nodeLimit);
         if (COUNT)
             ++counters.nodes;
         GlobalUint4 np = globalView(nodes + node);
@@ -411,7 +407,10 @@ struct Traversal {
         const uint32_t yhi0 = ny ? n2.z : n4.x, yhi1 = ny ? n2.w : n4.y;
         const uint32_t zlo0 = nz ? n4.z : n3.x, zlo1 = nz ? n4.w : n3.y;
         const uint32_t zhi0 = nz ? n3.x : n4.z, zhi1 = nz ? n3.y : n4.w;
-        float tnear[kWide];
+        // per child: the entry distance with the slot number in its low three
+        // bits (all ones when the ray misses the child), so that sorting the
+        // words sorts the children by distance
+        uint32_t key[kWide];
         uint32_t hitMask = 0;
 #pragma unroll
         for (int i = 0; i < kWide; ++i) {
@@ -428,63 +427,59 @@ struct Traversal {
             const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
             const uint32_t meta = ((i < 4 ? n1.z : n1.w) >> sh) & 0xffU;
             const bool present = ((imask >> i) & 1U) || (meta >> 5) != 0U;
-            tnear[i] = tn;
-            hitMask |= (present && tn <= tf) ? (1U << i) : 0U;
+            const bool hit = present && tn <= tf;
+            key[i] = hit ? ((__float_as_uint(tn) & ~7U) | static_cast<uint32_t>(i)) : 0xffffffffU;
+            hitMask |= hit ? (1U << i) : 0U;
         }
-        auto refOf = [&](int i) -> uint32_t {
-            const uint32_t meta = byteOf(n1.z, n1.w, i);
-            if ((imask >> i) & 1U)
-                return n1.x + meta;
-            return kLeafBit | (meta >> 5) << 28 | (n1.y + (meta & 31U));
+        // reference of the child in `slot`; its meta byte is byte `slot` of n1.z : n1.w
+        auto refOf = [&](uint32_t slot) -> uint32_t {
+            const uint32_t meta = __builtin_amdgcn_perm(n1.w, n1.z, 0x0c0c0c00U | slot);
+            const uint32_t inner = n1.x + meta;
+            const uint32_t leaf = kLeafBit | (meta >> 5) << 28 | (n1.y + (meta & 31U));
+            return ((imask >> slot) & 1U) ? inner : leaf;
         };
         if (hitMask == 0U) {
             node = kPop;
             return;
         }
-#if RT_TRACE_SORTED_PUSH
-        // push all but the nearest, farthest first
-        while (hitMask & (hitMask - 1U)) {
-            RT_SITE(1);
-            float far = -INFINITY;
-            int which = 0;
-#pragma unroll
-            for (int i = 0; i < kWide; ++i)
-                if (((hitMask >> i) & 1U) && tnear[i] >= far) {
-                    far = tnear[i];
-                    which = i;
-                }
-            push(refOf(which), far);
-            hitMask &= ~(1U << which);
+        if ((hitMask & (hitMask - 1U)) == 0U) {
+            node = refOf(static_cast<uint32_t>(__ffs(static_cast<int>(hitMask)) - 1));
+            return;
         }
-        node = refOf(__ffs(static_cast<int>(hitMask)) - 1);
-#else
-        // enter the nearest, push the others in slot order
-        float nearest = INFINITY;
-        int which = 0;
+        RT_SITE(1);
+        // several children: sort them (19 compare-exchanges), enter the nearest
+        // and leave the others on the stack, farthest first
+#define RT_EXCHANGE(a, b)                                                      \
+    do {                                                                       \
+        const uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]);     \
+        key[a] = lo;                                                           \
+        key[b] = hi;                                                           \
+    } while (0)
+        RT_EXCHANGE(0, 1); RT_EXCHANGE(2, 3); RT_EXCHANGE(4, 5); RT_EXCHANGE(6, 7);
+        RT_EXCHANGE(0, 2); RT_EXCHANGE(1, 3); RT_EXCHANGE(4, 6); RT_EXCHANGE(5, 7);
+        RT_EXCHANGE(1, 2); RT_EXCHANGE(5, 6); RT_EXCHANGE(0, 4); RT_EXCHANGE(3, 7);
+        RT_EXCHANGE(1, 5); RT_EXCHANGE(2, 6);
+        RT_EXCHANGE(1, 4); RT_EXCHANGE(3, 6);
+        RT_EXCHANGE(2, 4); RT_EXCHANGE(3, 5);
+        RT_EXCHANGE(3, 4);
+#undef RT_EXCHANGE
 #pragma unroll
-        for (int i = 0; i < kWide; ++i)
-            if (((hitMask >> i) & 1U) && tnear[i] < nearest) {
-                nearest = tnear[i];
-                which = i;
+        for (int j = kWide - 1; j >= 1; --j) {
+            if (key[j] != 0xffffffffU) {
+                // the distance lost its low bits, which only lowers it; a negative
+                // one (ray interval starting behind the origin) would be raised, so
+                // it is replaced by one that never drops the entry
+                const float t = static_cast<int>(key[j]) < 0 ? -INFINITY : __uint_as_float(key[j] & ~7U);
+                push(refOf(key[j] & 7U), t);
             }
-        hitMask &= ~(1U << which);
-        while (hitMask) {
-            const int i = __ffs(static_cast<int>(hitMask)) - 1;
-            hitMask &= hitMask - 1U;
-            float t = tnear[0];
-#pragma unroll
-            for (int k = 1; k < kWide; ++k)
-                t = i == k ? tnear[k] : t;
-            push(refOf(i), t);
         }
-        node = refOf(which);
-#endif
+        node = refOf(key[0] & 7U);
     }
 
     // Top-level leaf: move the ray into the instance's object space.
     __device__ __forceinline__ void enterInstance() {
         RT_SITE(4);
-        RT_GUARD((node & 0x0fffffffU) < instanceLimit);
+        RT_GUARD((node & 0x0fffffffU) < itemLimit);
         if (COUNT)
             ++counters.instances;
         const InstanceRecord* record = instances + (node & 0x0fffffffU);
@@ -508,7 +503,7 @@ struct Traversal {
         triangles = reinterpret_cast<const PackedTriangle*>(static_cast<uintptr_t>(q3.z) | static_cast<uintptr_t>(q3.w) << 32);
         instanceId = q4.x;
         nodeLimit = q4.z;
-        triangleLimit = q4.w;
+        itemLimit = q4.w;
         inBottom = true;
         node = 0;
     }
@@ -521,7 +516,7 @@ struct Traversal {
             ++counters.triangles;
         const uint32_t count = (node >> 28) & 7U;
         const uint32_t first = node & 0x0fffffffU;
-        RT_GUARD(first < triangleLimit);
+        RT_GUARD(first < itemLimit);
         GlobalUint4 tp = globalView(triangles + first);
         const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
         float t, u, v;
