@@ -44,12 +44,9 @@ namespace rt {
 #ifndef RT_TRACE_REFILL
 #define RT_TRACE_REFILL 32
 #endif
-// Triangles a lane may test per turn, and whether a turn starts by reading the stack.
+// Triangles a lane may test per turn.
 #ifndef RT_TRACE_LEAF_STEPS
 #define RT_TRACE_LEAF_STEPS 2
-#endif
-#ifndef RT_TRACE_ORDER
-#define RT_TRACE_ORDER 0
 #endif
 // Workgroups launched per resident workgroup slot (1 = exactly one resident set).
 #ifndef RT_TRACE_GRID_SCALE
@@ -339,40 +336,39 @@ struct Traversal {
         ++sp;
     }
 
-    // Next entry that can still matter, or kDone.  Leaving an instance restores
-    // the world-space ray.
+    // Takes one entry off the stack: the reference to go to, kPop when the entry
+    // needs no visit (it fell behind the closest hit, or it marked the end of an
+    // instance, which restores the world-space ray) or kDone when nothing is left.
+    // One entry per call: a loop here would hold the wave's other lanes up.
     __device__ __forceinline__ uint32_t pop() {
-        for (;;) {
-            RT_SITE(2);
-            if (sp == 0)
-                return kDone;
-            --sp;
-            if (sp >= kMaxStack)
-                continue;  // never pushed (guarded against on the host as well)
-            uint32_t ref;
-            float t;
-            if (sp < kLdsStack) {
-                ref = stackRef[sp * stride];
-                t = stackT[sp * stride];
-            } else {
-                ref = privateRef[sp - kLdsStack];
-                t = privateT[sp - kLdsStack];
-            }
-            if (ref == kSentinel) {
-                cur = world;
-                idx = __builtin_amdgcn_rcpf(cur.dx);
-                idy = __builtin_amdgcn_rcpf(cur.dy);
-                idz = __builtin_amdgcn_rcpf(cur.dz);
-                nodes = topNodes;
-                nodeLimit = topNodeLimit;
-                itemLimit = instanceLimit;
-                inBottom = false;
-                continue;
-            }
-            if (t > bestT * kGrow)
-                continue;  // fell behind the closest hit found since
-            return ref;
+        RT_SITE(2);
+        if (sp == 0)
+            return kDone;
+        --sp;
+        const uint32_t otherwise = sp == 0 ? kDone : kPop;
+        if (sp >= kMaxStack)
+            return otherwise;  // never pushed (guarded against on the host as well)
+        uint32_t ref;
+        float t;
+        if (sp < kLdsStack) {
+            ref = stackRef[sp * stride];
+            t = stackT[sp * stride];
+        } else {
+            ref = privateRef[sp - kLdsStack];
+            t = privateT[sp - kLdsStack];
         }
+        if (ref == kSentinel) {
+            cur = world;
+            idx = __builtin_amdgcn_rcpf(cur.dx);
+            idy = __builtin_amdgcn_rcpf(cur.dy);
+            idz = __builtin_amdgcn_rcpf(cur.dz);
+            nodes = topNodes;
+            nodeLimit = topNodeLimit;
+            itemLimit = instanceLimit;
+            inBottom = false;
+            return otherwise;
+        }
+        return t > bestT * kGrow ? otherwise : ref;
     }
 
     // One wide node: intersect the eight child boxes, continue with the nearest
@@ -634,10 +630,6 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             // a burst: a few wide nodes, then at most one leaf.  A step that
             // runs out of work leaves kPop behind, and the stack is read at one
             // place only, so that the lanes which need it go there together.
-#if RT_TRACE_ORDER == 1
-            if (walk.node == kPop)
-                walk.node = walk.pop();
-#endif
 #pragma unroll 1
             for (int s = 0; s < RT_TRACE_NODE_STEPS; ++s) {
                 if (!(walk.node & kLeafBit))
