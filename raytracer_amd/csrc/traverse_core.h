@@ -54,8 +54,11 @@ namespace rt {
 #endif
 
 constexpr int kTraceBlock = 256;
-constexpr int kLdsStack = 12;       // entries per lane kept in LDS
-constexpr int kPrivateStack = 116;  // overflow entries per lane in private memory
+#ifndef RT_TRACE_LDS_STACK
+#define RT_TRACE_LDS_STACK 12
+#endif
+constexpr int kLdsStack = RT_TRACE_LDS_STACK;  // entries per lane kept in LDS
+constexpr int kPrivateStack = 128 - kLdsStack;  // overflow entries per lane in private memory
 constexpr int kMaxStack = kLdsStack + kPrivateStack;
 constexpr uint32_t kLeafBit = 0x80000000U;
 constexpr uint32_t kSentinel = 0x7fffffffU;  // marks the return from an instance
