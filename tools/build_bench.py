@@ -15,7 +15,9 @@ from helpers import engine_scene
 
 def one(name, scene, builder, rays=1 << 21):
     os.environ["RT_BLAS_BUILDER"] = builder
+    print(f"{name}: building", flush=True)
     top, blases = engine_scene(engine, scene)
+    print(f"{name}: built, generating rays", flush=True)
     build = sum(b.stats().buildMilliseconds for b in blases)
     nodes = sum(b.stats().nodeCount for b in blases)
     depth = max(getattr(b.stats(), "depth", -1) for b in blases)
@@ -39,6 +41,7 @@ def main():
     engine.load()
     if len(sys.argv) > 1:  # soup sizes on the command line, default builder only: the large-scene measurements
         for n in (int(a) for a in sys.argv[1:]):
+            print(f"soup {n}: generating triangles", flush=True)
             one(f"soup {n}", workloads.triangle_soup(n), "radix", rays=1 << 24)
         return
     cases = [("tube 871k", workloads.dragon_cornell()), ("soup 100k", workloads.triangle_soup(100000)),
