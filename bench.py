@@ -188,6 +188,10 @@ def main():
         renderer.set_photon_budget(1 << 24, 1 << 23, 1 << 22)
 
     # traversal averages per ray (for the algorithmic byte count), outside the timed region
+    if profile == R.FINAL:
+        # sample 0 starts with a photon pass, whose rays the traversal counters do not see
+        renderer.render()
+        renderer.statistics()
     renderer.set_measurement(count_traversal=True)
     renderer.render()
     c = renderer.statistics()
