@@ -317,6 +317,17 @@ int rth_decode_png(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t*
     });
 }
 
+int rth_decode_jpeg(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height, uint8_t* out) {
+    return guarded([&] {
+        std::vector<std::byte> file(reinterpret_cast<const std::byte*>(bytes), reinterpret_cast<const std::byte*>(bytes) + size);
+        std::vector<std::uint8_t> rgba;
+        if (!rt::decodeJpegImage(file, rgba, *width, *height))
+            throw std::runtime_error("not a JPEG this reader handles");
+        if (out)
+            std::memcpy(out, rgba.data(), rgba.size());
+    });
+}
+
 int rth_decode_hdr(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height, float* out) {
     return guarded([&] {
         std::vector<std::byte> file(reinterpret_cast<const std::byte*>(bytes), reinterpret_cast<const std::byte*>(bytes) + size);

@@ -9,7 +9,7 @@
 // reference leans on fastgltf, simdjson and stb_image for those parts.
 //
 // Not supported (an exception says so): sparse accessors, Draco / meshopt
-// compression, JPEG and KTX2 images (they stay encoded), orthographic cameras.
+// compression, KTX2 and DDS images (they stay encoded), orthographic cameras.
 #include "scene.hpp"
 
 #include <zlib.h>
@@ -993,7 +993,8 @@ Image image(const Asset& asset, const Json& source) {  // scene.cpp:229-256
     }
     // Decoded here when the format is one this loader reads; other formats stay
     // encoded (the renderer then reports the texture as undecodable).
-    if (!decodePng(result.encoded, result.rgba, result.width, result.height)) {
+    if (!decodePng(result.encoded, result.rgba, result.width, result.height) &&
+        !decodeJpegImage(result.encoded, result.rgba, result.width, result.height)) {
         result.rgba.clear();
         result.width = result.height = 0;
     }

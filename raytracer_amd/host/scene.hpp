@@ -149,10 +149,14 @@ struct Scene {
 // environment named by `raytracer_hdri` must be a Radiance .hdr file.
 Scene loadScene(const std::filesystem::path& path);
 
-// The two image readers the loader uses, exposed for tests and tools.
+// The image readers the loader uses, exposed for tests and tools.
 // PNG -> RGBA8, row 0 = top row; false when the file is not a PNG this reader handles.
 bool decodePngImage(const std::vector<std::byte>& file, std::vector<std::uint8_t>& rgba, std::uint32_t& width,
                     std::uint32_t& height);
+// JPEG (baseline, extended sequential or progressive Huffman, grey or three components) -> RGBA8,
+// row 0 = top row, alpha 255 (jpeg.cpp).
+bool decodeJpegImage(const std::vector<std::byte>& file, std::vector<std::uint8_t>& rgba, std::uint32_t& width,
+                     std::uint32_t& height);
 // Radiance RGBE -> float RGBA (alpha 1), rows in file order.
 bool decodeRadianceImage(const std::vector<std::byte>& file, std::vector<Vec4>& pixels, std::uint32_t& width,
                          std::uint32_t& height);

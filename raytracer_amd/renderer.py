@@ -95,6 +95,7 @@ _SIG = {
     "rth_scene_get_texture": (C.c_int, [_vp, _u32, _vp]),
     "rth_scene_get_environment": (C.c_int, [_vp, _vp, _vp]),
     "rth_decode_png": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
+    "rth_decode_jpeg": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
     "rth_decode_hdr": (C.c_int, [_vp, C.c_size_t, C.POINTER(_u32), C.POINTER(_u32), _vp]),
     "rth_write_png": (C.c_int, [C.c_char_p, _u32, _u32, _vp]),
     "rth_write_exr": (C.c_int, [C.c_char_p, _u32, _u32, _vp]),
@@ -307,6 +308,17 @@ def decode_png(data):
     _check(lib.rth_decode_png(_p(buf), buf.size, C.byref(w), C.byref(h), None))
     out = np.empty((h.value, w.value, 4), dtype=np.uint8)
     _check(lib.rth_decode_png(_p(buf), buf.size, C.byref(w), C.byref(h), _p(out)))
+    return out
+
+
+def decode_jpeg(data):
+    """The loader's JPEG reader on a bytes object: (height, width, 4) uint8."""
+    lib = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    w, h = _u32(0), _u32(0)
+    _check(lib.rth_decode_jpeg(_p(buf), buf.size, C.byref(w), C.byref(h), None))
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    _check(lib.rth_decode_jpeg(_p(buf), buf.size, C.byref(w), C.byref(h), _p(out)))
     return out
 
 

@@ -280,6 +280,40 @@ def test_png_reader(R):
         R.decode_png(truncated)
 
 
+def test_jpeg_reader(R, tmp_path):
+    """Every kind of file the reader handles (baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, restart
+    intervals, optimised tables, sizes that are no multiple of the MCU), against the pixels libjpeg-turbo
+    decodes from the same bytes (tests/golden/make_jpeg_fixtures.py): the reader uses the same integer
+    inverse DCT, chroma filter and colour tables, so the comparison is exact.  What stb_image, the
+    reference's decoder, would give for these files is not pinned by anything the reference holds."""
+    fixtures = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_fixtures.npz"))
+    names = sorted(k[:-5] for k in fixtures.files if k.endswith("_file"))
+    assert len(names) == 11
+    for name in names:
+        got = R.decode_jpeg(fixtures[name + "_file"].tobytes())
+        want = fixtures[name + "_rgb"]
+        assert got.shape == want.shape[:2] + (4,), name
+        assert np.array_equal(got[..., :3], want), name
+        assert (got[..., 3] == 255).all(), name
+    for bad in (b"\xff\xd8", b"\xff\xd8\xff\xd9", b"not a jpeg at all" * 4):
+        with pytest.raises(engine.EngineError):
+            R.decode_jpeg(bad)
+    # a JPEG texture in a scene arrives decoded, like a PNG one
+    scene = workloads.cornell_box()
+    data = fixtures["baseline_420_file"].tobytes()
+    path = write_scene(scene, tmp_path / "jpeg.gltf", container="gltf")
+    document = json.load(open(path))
+    open(tmp_path / "wall.jpg", "wb").write(data)
+    document["images"] = [{"uri": "wall.jpg"}]
+    document["textures"] = [{"source": 0}]
+    document["materials"][0]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    json.dump(document, open(path, "w"))
+    loaded = R.load_scene(path)
+    image = loaded.image(0)
+    assert image["width"] == 61 and image["height"] == 43
+    assert np.array_equal(image["rgba"][..., :3], fixtures["baseline_420_rgb"])
+
+
 def test_hdr_reader(R):
     rng = np.random.default_rng(4)
     pixels = (rng.random((19, 40, 3)) ** 4 * 50.0).astype(np.float32)
