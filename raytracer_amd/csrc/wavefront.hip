@@ -79,6 +79,34 @@ __device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t*
     return slot;
 }
 
+// Two queues at once (the next bounce's rays and the shadow rays of a shade
+// launch): one pass through the workgroup's barriers instead of two.  `shared`
+// holds 16 words.
+__device__ inline void allocateSlotPair(bool wantA, uint32_t* counterA, bool wantB, uint32_t* counterB,
+                                        uint32_t* shared /* 16 words */, uint32_t& slotA, uint32_t& slotB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votesA = __ballot(wantA), votesB = __ballot(wantB);
+    if (lane == 0) {
+        shared[wave] = __popcll(votesA);
+        shared[8 + wave] = __popcll(votesB);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {  // thread 0 totals queue A, thread 1 queue B
+        uint32_t* counts = shared + 8 * threadIdx.x;
+        uint32_t total = 0;
+        for (int w = 0; w < kShadeBlock / 64; ++w) {
+            const uint32_t c = counts[w];
+            counts[w] = total;
+            total += c;
+        }
+        counts[4] = total ? atomicAdd(threadIdx.x == 0 ? counterA : counterB, total) : 0U;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    slotA = shared[4] + shared[wave] + __popcll(votesA & below);
+    slotB = shared[12] + shared[8 + wave] + __popcll(votesB & below);
+}
+
 // ---- camera paths -----------------------------------------------------------
 
 // Pixel of path i of a launch over [pixelBegin, pixelBegin + count).  Paths are
@@ -255,7 +283,7 @@ __device__ inline bool lightTriangleDistance(const ShadeInstance* instances, con
 __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                            const rt_hit_group_data* geometries, Buffers b, int which,
                                                            uint32_t depth) {
-    __shared__ uint32_t slots[8];
+    __shared__ uint32_t slots[16];
     const uint32_t n = b.counts[which];
     if (blockIdx.x * kShadeBlock >= n)
         return;  // whole workgroup idle
@@ -428,13 +456,13 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     }
 
     const int next = which ^ 1;
-    const uint32_t nextSlot = allocateSlots(continues, &b.counts[next], slots);
+    uint32_t nextSlot, shadowSlot;
+    allocateSlotPair(continues, &b.counts[next], wantsShadow, &b.counts[2], slots, nextSlot, shadowSlot);
     if (continues) {
         b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
         b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
         b.rayPath[next][nextSlot] = path;
     }
-    const uint32_t shadowSlot = allocateSlots(wantsShadow, &b.counts[2], slots);
     if (wantsShadow) {
         b.shadowOrigin[shadowSlot] = make_float4(shadowOrigin.x, shadowOrigin.y, shadowOrigin.z, 0.001f);
         b.shadowDirection[shadowSlot] = make_float4(shadowDirection.x, shadowDirection.y, shadowDirection.z, shadowLimit);
