@@ -887,9 +887,9 @@ float scaleOfHost(uint8_t e) {
     return v;
 }
 
-// Median-split tree over instance boxes written straight into wide nodes:
-// every node takes up to eight children by repeatedly splitting the group with
-// the largest box; a group of one instance is a leaf child.
+// Tree over instance boxes written straight into wide nodes: every node takes up
+// to eight children by repeatedly splitting the group with the largest box (see
+// split()); a group of one instance is a leaf child.
 struct TopBuilder {
     const std::vector<Aabb>& boxes;
     std::vector<uint32_t> order;      // instance permutation the splits work on
@@ -919,27 +919,73 @@ struct TopBuilder {
         return x * y + y * z + z * x;
     }
 
+    // Cuts a group in two.  Up to kSweepLimit instances the cut is the one of least
+    // surface-area cost, area(left) * |left| + area(right) * |right|, over all three
+    // axes and every position in centroid order (a full sweep: instances of very
+    // different sizes, a room around a field of small objects, are told apart where
+    // a median cut would put them in overlapping halves); larger groups are cut at
+    // the median of the axis their centroids spread most along.
+    static constexpr uint32_t kSweepLimit = 4096;
+
+    void sortAlong(const Group& g, int axis) {
+        std::sort(order.begin() + g.first, order.begin() + g.first + g.count, [&](uint32_t x, uint32_t y) {
+            const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
+            const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+    }
+
     void split(const Group& g, Group& l, Group& r) {
-        Aabb centers = emptyBox();
-        for (uint32_t i = g.first; i < g.first + g.count; ++i) {
-            const Aabb& b = boxes[order[i]];
-            for (int a = 0; a < 3; ++a) {
-                const float c = 0.5f * (b.lo[a] + b.hi[a]);
-                centers.lo[a] = std::min(centers.lo[a], c);
-                centers.hi[a] = std::max(centers.hi[a], c);
+        uint32_t mid = g.first + g.count / 2;
+        if (g.count <= kSweepLimit) {
+            int bestAxis = -1;
+            uint32_t bestLeft = 0;
+            float bestCost = INFINITY;
+            std::vector<float> rightArea(g.count);
+            for (int axis = 0; axis < 3; ++axis) {
+                sortAlong(g, axis);
+                Aabb box = emptyBox();
+                for (uint32_t i = g.count; i-- > 1;) {
+                    growBox(box, boxes[order[g.first + i]]);
+                    rightArea[i] = area(box);
+                }
+                box = emptyBox();
+                for (uint32_t i = 1; i < g.count; ++i) {
+                    growBox(box, boxes[order[g.first + i - 1]]);
+                    const float cost = area(box) * static_cast<float>(i) + rightArea[i] * static_cast<float>(g.count - i);
+                    if (cost < bestCost) {
+                        bestCost = cost;
+                        bestAxis = axis;
+                        bestLeft = i;
+                    }
+                }
             }
+            if (bestAxis >= 0) {
+                if (bestAxis != 2)
+                    sortAlong(g, bestAxis);
+                mid = g.first + bestLeft;
+            }
+        } else {
+            Aabb centers = emptyBox();
+            for (uint32_t i = g.first; i < g.first + g.count; ++i) {
+                const Aabb& b = boxes[order[i]];
+                for (int a = 0; a < 3; ++a) {
+                    const float c = 0.5f * (b.lo[a] + b.hi[a]);
+                    centers.lo[a] = std::min(centers.lo[a], c);
+                    centers.hi[a] = std::max(centers.hi[a], c);
+                }
+            }
+            int axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (centers.hi[a] - centers.lo[a] > centers.hi[axis] - centers.lo[axis])
+                    axis = a;
+            std::nth_element(order.begin() + g.first, order.begin() + mid, order.begin() + g.first + g.count,
+                             [&](uint32_t x, uint32_t y) {
+                                 const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
+                                 const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+                                 return cx < cy || (cx == cy && x < y);
+                             });
         }
-        int axis = 0;
-        for (int a = 1; a < 3; ++a)
-            if (centers.hi[a] - centers.lo[a] > centers.hi[axis] - centers.lo[axis])
-                axis = a;
-        const uint32_t mid = g.first + g.count / 2;
-        std::nth_element(order.begin() + g.first, order.begin() + mid, order.begin() + g.first + g.count,
-                         [&](uint32_t x, uint32_t y) {
-                             const float cx = boxes[x].lo[axis] + boxes[x].hi[axis];
-                             const float cy = boxes[y].lo[axis] + boxes[y].hi[axis];
-                             return cx < cy || (cx == cy && x < y);
-                         });
         l = {g.first, mid - g.first, boxOf(g.first, mid - g.first)};
         r = {mid, g.first + g.count - mid, boxOf(mid, g.first + g.count - mid)};
     }
