@@ -36,11 +36,7 @@ namespace rt {
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 5
 #endif
-// Persistent launches: wide nodes a lane may walk per turn before its leaf, and
-// how many idle lanes make a wave fetch new rays.
-#ifndef RT_TRACE_NODE_STEPS
-#define RT_TRACE_NODE_STEPS 1
-#endif
+// Persistent launches: how many idle lanes make a wave fetch new rays.
 #ifndef RT_TRACE_REFILL
 #define RT_TRACE_REFILL 32
 #endif
@@ -598,9 +594,9 @@ struct RayFeed {
 // `index` and calls traversal.begin(...), returning false when the ray needs no
 // walk; store(index, result) consumes a finished ray.
 //
-// Per turn every lane with a ray runs a burst: up to RT_TRACE_NODE_STEPS wide
-// nodes, then at most one leaf, so the lanes of a wave run the node code
-// together and the leaf code together.
+// Per turn every lane with a ray does at most one wide node, one stack entry
+// and one leaf (up to RT_TRACE_LEAF_STEPS triangles of it), so the lanes of a
+// wave run the node code together and the leaf code together.
 template <bool COUNT, typename Fetch, typename Store>
 __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Fetch&& fetch, Store&& store) {
     bool active = false;
@@ -644,18 +640,15 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             uint32_t raySteps = 0;
             RT_SITE(5);
 #endif
-            // a burst: a few wide nodes, then at most one leaf.  A step that
-            // runs out of work leaves kPop behind, and the stack is read at one
-            // place only, so that the lanes which need it go there together.
-#pragma unroll 1
-            for (int s = 0; s < RT_TRACE_NODE_STEPS; ++s) {
-                if (!(walk.node & kLeafBit))
-                    walk.nodeStep();
-                if (walk.node == kPop)
-                    walk.node = walk.pop();
-                else if (walk.node & kLeafBit)
-                    break;
-            }
+            // A turn is flat: one wide node for the lanes at one, then one stack entry
+            // for the lanes that ran out of work (kPop), then the leaf code.  A loop
+            // at any of these places makes the other lanes of the wave wait for its
+            // longest trip, and the values the compiler keeps across it cost registers
+            // (three nodes per turn spilt 26-48 registers; this form spills none).
+            if (!(walk.node & kLeafBit))
+                walk.nodeStep();
+            if (walk.node == kPop)
+                walk.node = walk.pop();
             if ((walk.node & kLeafBit) && walk.node < kPop) {
                 if (!walk.inBottom) {
                     walk.enterInstance();
