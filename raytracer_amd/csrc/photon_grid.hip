@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void photonReorderKernel(const rt_photon* phot
 }
 
 // One query per lane.
-__global__ __launch_bounds__(256) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
+__global__ __launch_bounds__(256, 8) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
                                                           uint32_t bucketCount, float radius, const float* qpos,
                                                           const float* qnormal, uint32_t n, float* flux,
                                                           unsigned long long* visitedTotal) {
