@@ -154,6 +154,23 @@ def test_full_frame_properties_without_the_oracle(engine):
     assert s.triangleCount == 871212 and s.instanceCount == len(scene["instances"])
 
 
+def test_ragged_batch_sizes(engine, oracle):
+    """Batches around the sizes the ray feed is cut at: one ray, one wave's worth and one more, chunks
+    that are partly or wholly empty, fewer rays than the launch has waves (most of which then leave at
+    once) and a batch every wave draws from."""
+    scene = workloads.sphere_field(count=40, seed=9, subdivisions=2)
+    top, blases = engine_scene(engine, scene)
+    ref = oracle_scene(oracle, scene)
+    o, d = workloads.random_rays(scene, 400003, seed=12)
+    tuv, prim, rinst = ref.trace_closest(o, d, use_bvh=True, threads=8)
+    for n in (1, 2, 63, 64, 65, 129, 511, 513, 1000, 4097, 70001, 400003):
+        hits, inst = top.trace_closest(dev(o[:n]), dev(d[:n]))
+        bad, report = compare_closest(hits, inst, tuv[:n], prim[:n], rinst[:n])
+        assert bad == 0, f"{n} rays: {bad} differ: {report}"
+        occ = top.trace_any(dev(o[:n]), dev(d[:n])).cpu().numpy()
+        assert np.array_equal(occ, (prim[:n] != 0xffffffff).astype(np.uint8)), n
+
+
 def test_counters_and_empty_launch(engine, oracle):
     import torch
     scene = workloads.cornell_box()
