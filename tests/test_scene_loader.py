@@ -349,6 +349,21 @@ def test_readers_on_the_reference_assets(R):
         data = open(os.path.join(ASSETS, "hdri", name), "rb").read()
         got = R.decode_hdr(data)
         assert got.shape[:2] == shape and np.isfinite(got).all() and (got[..., 3] == 1.0).all() and got[..., :3].max() > 1.0
+    # the progressive JPEG pictures of the reference's readme, against libjpeg-turbo where Pillow is installed
+    pictures = os.path.join(os.path.dirname(ASSETS), "img", "github")
+    for name in ("dragon_cornell.jpg", "sphere_field.jpg"):
+        path = os.path.join(pictures, name)
+        if not os.path.isfile(path):
+            continue
+        data = open(path, "rb").read()
+        got = R.decode_jpeg(data)
+        assert got.shape == (720, 1280, 4) and (got[..., 3] == 255).all()
+        try:
+            import io
+            from PIL import Image
+        except ImportError:
+            continue
+        assert np.array_equal(got[..., :3], np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
 
 
 def read_exr(path):
