@@ -551,7 +551,7 @@ struct RayFeed {
     __device__ __forceinline__ RayFeed(uint32_t* c, uint32_t count) : cursors(c), n(count) {
         chunkSize = ((count + 7U) / 8U + 63U) & ~63U;
         chunk = blockIdx.x & 7U;
-        exhausted = 0;
+        exhausted = 0;  // chunk and exhausted go through readfirstlane wherever they change: scalar registers
     }
     __device__ __forceinline__ bool drained() const { return exhausted >= 8U; }
 
@@ -577,14 +577,14 @@ struct RayFeed {
             uint32_t base = 0;
             if (lane == 0)
                 base = atomicAdd(&cursors[chunk * kFeedStride], want);
-            base = __shfl(base, 0, 64);
+            base = __builtin_amdgcn_readfirstlane(base);
             if (base < end - begin) {
                 const uint32_t mine = begin + base + __popcll(idleMask & ((1ULL << lane) - 1ULL));
                 index = mine;
                 return idle && mine < end;
             }
-            ++exhausted;
-            chunk = (chunk + 1U) & 7U;
+            exhausted = __builtin_amdgcn_readfirstlane(exhausted + 1U);
+            chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) & 7U);
         }
         return false;
     }
