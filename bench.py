@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--workload", default="dragon-cornell",
                    choices=["dragon-cornell", "cornell", "sphere-field", "caustic-lab"])
     p.add_argument("--photons", type=int, default=1 << 23)
-    p.add_argument("--tiles", type=int, default=2,
+    p.add_argument("--tiles", type=int, default=3,
                    help="concurrent parts of the frame per render() call (1 = one stream)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-photon-bench", action="store_true")

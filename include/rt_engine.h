@@ -217,6 +217,14 @@ rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out8, int reset,
 #define RT_WAVEFRONT_TIME_STAGES 1u      /* bracket every stage launch of rt_render_sample with HIP events */
 #define RT_WAVEFRONT_COUNT_TRAVERSAL 2u  /* ray launches count visited nodes / tested triangles */
 rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
+/* Share of the GPU's wave slots a ray launch of this state occupies, as
+ * numerator / denominator of the resident set (default 1/1).  The ray stage
+ * runs in persistent waves that stay until the launch has drained, so two
+ * states rendering parts of a frame on two streams only run side by side when
+ * each leaves room for the other; rt::Renderer::render() sets 1/2 when it
+ * splits a frame (no counterpart upstream: the reference renders a frame
+ * with one launch, renderer.cpp:779-796). */
+rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
 /* Sums the event-timed launches since the last call per stage: [0] generate,
  * [1] trace (the shadow rays of a bounce and the closest-hit rays of the next
  * share one launch), [2] shade, [3] queue bookkeeping between bounces,

@@ -720,6 +720,7 @@ struct StageTiming {
 struct rt_wavefront {
     int device = 0;
     uint32_t flags = 0;               // RT_WAVEFRONT_TIME_STAGES | RT_WAVEFRONT_COUNT_TRAVERSAL
+    uint32_t shareNumerator = 1, shareDenominator = 1;  // part of the resident wave slots a ray launch takes
     std::vector<StageTiming> timings; // pending event pairs (flag TIME_STAGES)
     std::vector<hipEvent_t> eventPool;
     rt::Buffers buffers{};
@@ -822,6 +823,16 @@ rt_status rt_wavefront_configure(rt_wavefront* w, uint32_t flags) {
     if (!w)
         return failInvalid("null pointer");
     w->flags = flags;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32_t denominator) {
+    if (!w)
+        return failInvalid("null pointer");
+    if (numerator == 0 || denominator == 0 || numerator > denominator)
+        return failInvalid("the share of a ray launch is a fraction in (0, 1]");
+    w->shareNumerator = numerator;
+    w->shareDenominator = denominator;
     return RT_SUCCESS;
 }
 
@@ -947,7 +958,9 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     auto s = static_cast<hipStream_t>(stream);
     const Buffers& b = w->buffers;
     const unsigned blocks = divUp(count, kShadeBlock);
-    const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
+    const unsigned resident = std::max<unsigned>(
+        1U, static_cast<unsigned>(static_cast<uint64_t>(persistentBlocks(w->device)) * w->shareNumerator / w->shareDenominator));
+    const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), resident);
     const bool counted = w->flags & RT_WAVEFRONT_COUNT_TRAVERSAL;
     RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
     {

@@ -599,7 +599,7 @@ struct Renderer::Impl {
         rt_wavefront* wavefront = nullptr;
         hipStream_t stream = nullptr;
     };
-    static constexpr std::uint32_t DefaultTiles = 2;
+    static constexpr std::uint32_t DefaultTiles = 3;
     std::vector<Tile> tiles;
     rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
     std::uint32_t photonWavefrontCapacity = 0;
@@ -625,8 +625,12 @@ struct Renderer::Impl {
         for (auto& t : tiles) {
             engineCheck(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &t.wavefront), "rt_wavefront_create");
             engineCheck(rt_wavefront_configure(t.wavefront, measurementFlags), "rt_wavefront_configure");
-            if (count > 1)
+            if (count > 1) {
                 hipCheck(hipStreamCreate(&t.stream));  // a single tile stays on the default stream
+                // half the wave slots per ray launch: two parts of the frame then trace side by side,
+                // each filling the slots the other's last rays leave idle
+                engineCheck(rt_wavefront_set_ray_share(t.wavefront, 1, 2), "rt_wavefront_set_ray_share");
+            }
         }
     }
 

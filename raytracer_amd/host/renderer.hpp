@@ -49,7 +49,7 @@ public:
     void setSampleSequence(std::uint32_t first, std::uint32_t stride);
     // Restricts render() to the pixels [begin, end) in row-major order.
     void setPixelRange(std::uint32_t begin, std::uint32_t end);
-    // render() cuts its pixel range into `count` parts (1..8, default 2) that run
+    // render() cuts its pixel range into `count` parts (1..8, default 3) that run
     // concurrently on streams of their own; the image does not depend on it.
     // With more than one part the stage timings of the parts overlap in time.
     void setConcurrentTiles(std::uint32_t count);
