@@ -400,6 +400,9 @@ int rth_renderer_set_concurrent_tiles(rt::Renderer* r, uint32_t count) {
     return guarded([&] { r->setConcurrentTiles(count); });
 }
 uint32_t rth_renderer_concurrent_tiles(rt::Renderer* r) { return r->concurrentTiles(); }
+int rth_renderer_set_ray_share(rt::Renderer* r, uint32_t numerator, uint32_t denominator) {
+    return guarded([&] { r->setRayShare(numerator, denominator); });
+}
 void rth_renderer_set_manual_photon_passes(rt::Renderer* r, int manual) { r->setManualPhotonPasses(manual != 0); }
 int rth_renderer_photon_pass_due(rt::Renderer* r) { return r->photonPassDue() ? 1 : 0; }
 int rth_renderer_begin_photon_pass(rt::Renderer* r) { return guarded([&] { r->beginPhotonPass(); }); }

@@ -769,6 +769,10 @@ void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
     }
 }
 void Renderer::setConcurrentTiles(std::uint32_t count) { impl_->createTiles(count); }
+void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
+    for (auto& t : impl_->tiles)
+        engineCheck(rt_wavefront_set_ray_share(t.wavefront, numerator, denominator), "rt_wavefront_set_ray_share");
+}
 std::uint32_t Renderer::concurrentTiles() const { return static_cast<std::uint32_t>(impl_->tiles.size()); }
 void Renderer::synchronize() const { hipCheck(hipDeviceSynchronize()); }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }

@@ -53,6 +53,9 @@ public:
     // concurrently on streams of their own; the image does not depend on it.
     // With more than one part the stage timings of the parts overlap in time.
     void setConcurrentTiles(std::uint32_t count);
+    // Share of the GPU's wave slots a ray launch of one part takes (setConcurrentTiles
+    // resets it: 1/2 for a split frame, 1/1 otherwise).
+    void setRayShare(std::uint32_t numerator, std::uint32_t denominator);
     std::uint32_t concurrentTiles() const;
     // Splits a photon pass: render() then no longer runs it by itself; the
     // driver calls beginPhotonPass(), tracePhotonRange() for its share, places

@@ -114,6 +114,7 @@ _SIG = {
     "rth_renderer_set_pixel_range": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_concurrent_tiles": (C.c_int, [_vp, _u32]),
     "rth_renderer_concurrent_tiles": (_u32, [_vp]),
+    "rth_renderer_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
     "rth_renderer_begin_photon_pass": (C.c_int, [_vp]),
@@ -402,6 +403,10 @@ class Renderer:
 
     def set_concurrent_tiles(self, count):
         _check(load().rth_renderer_set_concurrent_tiles(self.handle, count))
+
+    def set_ray_share(self, numerator, denominator):
+        """Share of the GPU's wave slots a ray launch of one part of the frame takes (reset by set_concurrent_tiles)."""
+        _check(load().rth_renderer_set_ray_share(self.handle, numerator, denominator))
 
     def concurrent_tiles(self):
         return int(load().rth_renderer_concurrent_tiles(self.handle))
