@@ -216,6 +216,28 @@ def test_concurrent_tiles_do_not_change_the_image(R):
         assert stats["extend_rays"] == images[0][2]["extend_rays"] and stats["refused_references"] == 0
 
 
+def test_ray_share_does_not_change_the_image(R):
+    """The share of the wave slots a ray launch takes is a scheduling matter only: a small share makes
+    fewer waves walk the same rays.  Fractions outside (0, 1] are refused."""
+    from raytracer_amd import engine
+    scene = workloads.cornell_box(light="panel")
+    images = []
+    for tiles, share in ((1, (1, 1)), (3, (1, 2)), (2, (1, 7)), (1, (1, 1000))):
+        r = R.Renderer(scene, 96, 80)
+        r.set_concurrent_tiles(tiles)
+        r.set_ray_share(*share)
+        for _ in range(2):
+            r.render()
+        images.append(r.linear_pixels().copy())
+        assert r.statistics()["refused_references"] == 0
+    for pixels in images[1:]:
+        assert np.array_equal(pixels, images[0])
+    r = R.Renderer(scene, 32, 32)
+    for bad in ((0, 1), (1, 0), (3, 2)):
+        with pytest.raises(engine.EngineError):
+            r.set_ray_share(*bad)
+
+
 def test_scene_loaded_from_gltf_renders_the_same(R, tmp_path):
     """A scene that went through the glTF writer and rt::loadScene renders bit-identically to the scene
     built directly (PNG texture and Radiance environment included; the environment is compared after the
