@@ -225,6 +225,13 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
+/* Whether kernels put on these HIP streams (at most 16) really run side by
+ * side: a process has a limited number of hardware queues, streams beyond
+ * that number share one, and work on two streams of one queue runs in turn.
+ * Starts one 200-microsecond single-wave kernel per stream and times the lot
+ * (synchronises the device).  rt::Renderer uses it to pick streams for the
+ * parts of a split frame (no counterpart upstream). */
+rt_status rt_streams_run_concurrently(void* const* streams, uint32_t count, int* concurrent);
 /* Sums the event-timed launches since the last call per stage: [0] generate,
  * [1] trace (the shadow rays of a bounce and the closest-hit rays of the next
  * share one launch), [2] shade, [3] queue bookkeeping between bounces,

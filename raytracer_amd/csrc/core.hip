@@ -10,9 +10,53 @@ void setLastError(const std::string& message) {
     lastError = message;
 }
 
+namespace {
+// Keeps one wave busy for `ticks` of the 100 MHz clock (bounded by an iteration
+// count in case the clock does not advance).
+__global__ void occupyKernel(unsigned long long ticks, unsigned int* sink) {
+    const unsigned long long begin = wall_clock64();
+    unsigned int spins = 0;
+    while (wall_clock64() - begin < ticks && spins < (1U << 22))
+        ++spins;
+    if (sink && spins == 0xffffffffU)
+        *sink = spins;
+}
+}  // namespace
+
 }  // namespace rt
 
 extern "C" {
+
+rt_status rt_streams_run_concurrently(void* const* streams, uint32_t count, int* concurrent) {
+    if (!streams || !concurrent || count == 0 || count > 16)
+        return rt::failInvalid("streams / concurrent / count");
+    *concurrent = 1;
+    if (count == 1)
+        return RT_SUCCESS;
+    // one short wave per stream, started together: side by side they take the
+    // time of one, through a shared hardware queue the time of several
+    constexpr unsigned long long kTicks = 20000;  // 200 us
+    hipEvent_t start = nullptr, stop = nullptr;
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipEventCreate(&start));
+    RT_HIP(hipEventCreate(&stop));
+    float best = 1e30f;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        RT_HIP(hipEventRecord(start, nullptr));  // the blocking default stream orders against all of them
+        for (uint32_t k = 0; k < count; ++k)
+            hipLaunchKernelGGL(rt::occupyKernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(streams[k]), kTicks,
+                               static_cast<unsigned int*>(nullptr));
+        RT_HIP(hipEventRecord(stop, nullptr));
+        RT_HIP(hipEventSynchronize(stop));
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, start, stop));
+        best = ms < best ? ms : best;
+    }
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    *concurrent = best < 0.2f * 1.6f ? 1 : 0;
+    return RT_SUCCESS;
+}
 
 const char* rt_last_error(void) {
     return rt::lastError.c_str();

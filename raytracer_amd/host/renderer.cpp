@@ -622,16 +622,49 @@ struct Renderer::Impl {
         count = std::max<std::uint32_t>(1U, std::min<std::uint32_t>(count, 8U));
         const std::size_t capacity = (pixels + count - 1) / count;
         tiles.resize(count);
+        if (count > 1)
+            pickStreams();
         for (auto& t : tiles) {
             engineCheck(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &t.wavefront), "rt_wavefront_create");
             engineCheck(rt_wavefront_configure(t.wavefront, measurementFlags), "rt_wavefront_configure");
-            if (count > 1) {
-                hipCheck(hipStreamCreate(&t.stream));  // a single tile stays on the default stream
-                // half the wave slots per ray launch: two parts of the frame then trace side by side,
-                // each filling the slots the other's last rays leave idle
+            // a single tile stays on the default stream; the parts of a split frame take half the
+            // wave slots per ray launch: two of them then trace side by side, each filling the slots
+            // the other's last rays leave idle
+            if (count > 1)
                 engineCheck(rt_wavefront_set_ray_share(t.wavefront, 1, 2), "rt_wavefront_set_ray_share");
-            }
         }
+    }
+
+    // One stream per tile, chosen so that they run side by side.  A process has a
+    // few hardware queues (four by default) which its streams are dealt onto in
+    // turn; when other code of the process (a collective library, the caller's own
+    // streams) has taken some, two of a fresh set of streams can land on one queue
+    // and their parts of the frame then run one after the other (measured: 5.3
+    // instead of 3.7 ms per step).  So a set is probed, and a set that shares a
+    // queue is parked - which moves the next set one place on - until one is clean
+    // or a handful of sets has been tried; the last set is kept in that case.
+    void pickStreams() {
+        std::vector<hipStream_t> parked;
+        for (int attempt = 0;; ++attempt) {
+            std::vector<void*> set;
+            for (auto& t : tiles) {
+                hipCheck(hipStreamCreate(&t.stream));
+                set.push_back(t.stream);
+            }
+            int concurrent = 0;
+            engineCheck(rt_streams_run_concurrently(set.data(), static_cast<std::uint32_t>(set.size()), &concurrent),
+                        "rt_streams_run_concurrently");
+            if (concurrent || attempt == 5)
+                break;
+            // keep one stream of the failed set alive so that the next set starts one queue further
+            parked.push_back(tiles[0].stream);
+            for (std::size_t k = 1; k < tiles.size(); ++k)
+                (void)hipStreamDestroy(tiles[k].stream);
+            for (auto& t : tiles)
+                t.stream = nullptr;
+        }
+        for (hipStream_t s : parked)
+            (void)hipStreamDestroy(s);
     }
 
     std::vector<GeometryState> geometries;
