@@ -171,6 +171,38 @@ def test_ragged_batch_sizes(engine, oracle):
         assert np.array_equal(occ, (prim[:n] != 0xffffffff).astype(np.uint8)), n
 
 
+def soup_scene(points):
+    """A one-geometry scene from (n, 3, 3) triangle corners."""
+    p = np.asarray(points, dtype=np.float32).reshape(-1, 3)
+    idx = np.arange(len(p), dtype=np.uint32).reshape(-1, 3)
+    return dict(geometries=[{"vertices": workloads.make_vertices(p), "indices": idx, "material": 0}],
+                instances=[(0, np.eye(4, dtype=np.float32).reshape(-1))], materials=[workloads.default_material()],
+                lights=[], cameras=[], environment=None)
+
+
+def test_degenerate_geometry(engine, oracle):
+    """Geometry that stresses the builder rather than the rays: many copies of one triangle (equal Morton
+    codes, equal distances: the tie policy decides), zero-area and needle triangles, a mesh far from the
+    origin, and triangles of very different sizes in one geometry."""
+    rng = np.random.default_rng(21)
+    base = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    copies = np.repeat(base[None], 3000, axis=0)
+    needles = rng.uniform(-1, 1, (500, 1, 3)) + np.array([[0, 0, 0], [1e-6, 0, 0], [2.0, 2e-6, 0]])[None]
+    points = rng.uniform(-1, 1, (300, 1, 3)) + np.zeros((1, 3, 3))  # three equal corners
+    lines = rng.uniform(-1, 1, (300, 1, 3)) + np.array([[0, 0, 0], [0.5, 0.5, 0.5], [1.0, 1.0, 1.0]])[None]
+    tiny = rng.uniform(-1, 1, (2000, 1, 3)) + rng.normal(0, 1e-4, (2000, 3, 3))
+    huge = rng.uniform(-50, 50, (20, 3, 3))
+    far = workloads.triangle_soup(2000, seed=5)["geometries"][0]["vertices"][:, :3].reshape(-1, 3, 3) + 1.0e5
+    for name, tris in (("copies", copies), ("needles + points + lines", np.concatenate([needles, points, lines, tiny[:200]])),
+                       ("mixed sizes", np.concatenate([tiny, huge])), ("far from the origin", far)):
+        scene = soup_scene(tris)
+        o, d = workloads.random_rays(scene, 60000, seed=3)
+        # some rays straight at the shared triangle / along coordinate planes
+        o[:1000, :3] = [0.25, 0.25, 1.0] + (tris.reshape(-1, 3).mean(0) - [1 / 3, 1 / 3, 0]) * (name == "far from the origin")
+        d[:1000, :3] = [0.0, 0.0, -1.0]
+        check_scene(engine, oracle, scene, (o, d), brute=len(tris) <= 4000)
+
+
 def test_counters_and_empty_launch(engine, oracle):
     import torch
     scene = workloads.cornell_box()
