@@ -67,6 +67,32 @@ def test_axis_aligned_and_degenerate_rays(engine, oracle):
     check_scene(engine, oracle, scene, (org, dr), brute=True)
 
 
+def test_hostile_rays(engine, oracle):
+    """Rays a caller should not send but may: NaN and infinite components, an empty or reversed interval,
+    a negative tmin, denormal directions.  Nothing may fault, no reference may be refused, and whatever
+    the walk reports must be what the scalar restatement reports."""
+    scene = workloads.sphere_field(count=30, seed=4, subdivisions=2)
+    o, d = workloads.random_rays(scene, 40000, seed=8)
+    nan, inf = np.float32("nan"), np.float32("inf")
+    k = 0
+    for values in ((nan, 0, 0), (0, nan, 0), (inf, 0, 0), (-inf, 1, 1)):
+        for target in (o, d):
+            target[k * 50:(k + 1) * 50, :3] = np.where(np.isfinite(values) & (np.array(values) == 0), target[k * 50:(k + 1) * 50, :3],
+                                                       np.array(values, dtype=np.float32))
+            k += 1
+    base = k * 50
+    o[base:base + 200, 3] = 5.0          # tmin beyond tmax
+    d[base:base + 200, 3] = 1.0
+    o[base + 200:base + 400, 3] = -10.0  # interval that starts behind the origin
+    d[base + 400:base + 600, 3] = 0.0    # empty interval
+    d[base + 600:base + 800, 3] = nan
+    o[base + 800:base + 1000, 3] = nan
+    d[base + 1000:base + 1200, :3] *= np.float32(1e-40)  # denormal direction
+    d[base + 1200:base + 1400, :3] *= np.float32(1e30)   # very long direction
+    top, _ = check_scene(engine, oracle, scene, (o, d))
+    assert top is not None
+
+
 def test_short_rays_tmax(engine, oracle):
     scene = workloads.cornell_box(light="panel")
     o, d = workloads.random_rays(scene, 100000, seed=9)
