@@ -57,7 +57,9 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
                                   static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
     }
     // Cells the sphere cannot reach are not read: every photon in them fails the
-    // distance test, so leaving them out changes no sum.  gap[a][d] is a lower
+    // distance test, so leaving them out changes no sum (for photon positions that
+    // are numbers: a NaN position passes `distance^2 >= r^2 -> skip` and would turn
+    // the sum into NaN wherever its bucket is read).  gap[a][d] is a lower
     // bound of the distance along axis a to the neighbour cell at offset d - 1,
     // shortened by a tolerance that covers the rounding of the cell assignment
     // (floor of an IEEE quotient) and of the products here; with coordinates too

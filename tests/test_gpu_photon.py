@@ -86,6 +86,44 @@ def test_gather_collisions(engine, oracle):
     assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
 
 
+def test_hostile_photons_and_queries(engine, oracle):
+    """Photons and queries outside anything a renderer produces: infinite photon coordinates (saturated cell
+    index), NaN and infinite query coordinates and normals, coordinates beyond the range where
+    neighbouring cells differ as floats (no cell may be skipped there), negative zero, and a radius so
+    small that every coordinate saturates the cell index.  A photon whose *position* is NaN is outside the
+    contract: the reference's test `distance^2 >= r^2 -> skip` lets it through, so it turns the flux of every
+    query that reads its bucket into NaN; the gather here does not read cells out of the query's reach, so
+    fewer queries would be poisoned."""
+    n, B = 60000, 1 << 12
+    ph = workloads.caustic_photons(n, seed=5, extent=0.5)
+    nan, inf = np.float32("nan"), np.float32("inf")
+    ph[200:400, 1] = inf
+    ph[400:600, 2] = -inf
+    ph[600:1200, :3] += np.float32(3.0e7)   # beyond 2^24 cells of size 0.01: neighbours collapse
+    ph[1200:1800, :3] *= np.float32(-1.0e12)
+    ph[1800:2000, :3] = np.float32(-0.0)
+    qp, qn = workloads.gather_queries(20000, seed=6, extent=0.5)
+    qp[:300] = ph[600:900, :3]
+    qp[300:600] = ph[1200:1500, :3]
+    qp[600:700, 0] = nan
+    qp[700:800, 1] = inf
+    qp[800:900] = np.float32(-0.0)
+    qp[900:1200] = ph[1800:2100, :3]
+    qn[1200:1300] = nan
+    for r in (0.01, 1e-30, 1e12):
+        grid = engine.PhotonGrid(n, B)
+        grid.build(dev(ph), r, sync=True)
+        offsets, srt = oracle.build_photon_grid(ph, r, B)
+        assert np.array_equal(u32(grid.offsets), offsets), r
+        assert np.array_equal(grid.sorted[:n].cpu().numpy().view(np.uint32), srt.view(np.uint32)), r
+        flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+        ref = oracle.photon_gather(srt, offsets, B, r, qp, qn, threads=8)
+        # bit for bit, except that a NaN is a NaN whatever its sign and payload
+        both_nan = np.isnan(flux) & np.isnan(ref)
+        assert np.array_equal(np.where(both_nan, 0, flux.view(np.uint32)), np.where(both_nan, 0, ref.view(np.uint32))), r
+        assert both_nan.any() and (~both_nan).any()
+
+
 def test_full_size_properties(engine, oracle):
     """Reference-size map (2^23 photons, 2^22 buckets): properties that need no
     full CPU pass, plus the oracle on a slice of the queries."""
