@@ -437,7 +437,12 @@ bool decodePng(const std::vector<std::byte>& file, std::vector<std::uint8_t>& rg
     const std::size_t bitsPerPixel = static_cast<std::size_t>(channels) * depth;
     const std::size_t stride = (static_cast<std::size_t>(width) * bitsPerPixel + 7) / 8;
     const std::size_t pixelBytes = std::max<std::size_t>(1, bitsPerPixel / 8);
-    std::vector<unsigned char> raw((stride + 1) * height);
+    // deflate expands by a factor of 1032 at most: a header that promises more pixels than
+    // the compressed data can hold is refused before anything of that size is allocated
+    const std::size_t rawBytes = (stride + 1) * static_cast<std::size_t>(height);
+    if (rawBytes / 1032 > compressed.size() + 1 || rawBytes > (std::size_t{1} << 32))
+        return false;
+    std::vector<unsigned char> raw(rawBytes);
     uLongf rawSize = static_cast<uLongf>(raw.size());
     if (uncompress(raw.data(), &rawSize, compressed.data(), static_cast<uLong>(compressed.size())) != Z_OK ||
         rawSize != raw.size())
@@ -541,6 +546,10 @@ bool decodeHdr(const std::vector<std::byte>& file, std::vector<Vec4>& pixels, st
     const std::string resolution = line();
     int h = 0, w = 0;
     if (std::sscanf(resolution.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0)
+        return false;
+    // a run of two bytes yields 127 channel values at most, a pixel has four: a header that promises
+    // more than 16 pixels per byte left in the file is refused before anything is allocated
+    if (at > file.size() || static_cast<std::uint64_t>(w) * static_cast<std::uint64_t>(h) > (file.size() - at) * 16ULL + 16ULL)
         return false;
     width = static_cast<std::uint32_t>(w);
     height = static_cast<std::uint32_t>(h);
