@@ -278,6 +278,12 @@ def test_png_reader(R):
     truncated = encode_png(image)[:200]
     with pytest.raises(engine.EngineError):
         R.decode_png(truncated)
+    # a header that promises 2^31 x 2^31 pixels over a few hundred bytes of data is refused, not allocated
+    data = bytearray(encode_png(image))
+    data[16:24] = struct.pack(">II", 1 << 31, 1 << 31)
+    data[29:33] = struct.pack(">I", zlib.crc32(bytes(data[12:29])))
+    with pytest.raises(engine.EngineError):
+        R.decode_png(bytes(data))
 
 
 def test_jpeg_reader(R, tmp_path):
@@ -329,6 +335,8 @@ def test_hdr_reader(R):
     assert np.array_equal(R.decode_hdr(encode_hdr(narrow)), rgbe_to_float(narrow))
     with pytest.raises(engine.EngineError):
         R.decode_hdr(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 1 +X 1\n\0\0\0\0")
+    with pytest.raises(engine.EngineError):  # more pixels promised than the file can hold
+        R.decode_hdr(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2000000000 +X 2000000000\n" + b"\2\2\0\10" * 16)
 
 
 ASSETS = "/root/reference/assets"
