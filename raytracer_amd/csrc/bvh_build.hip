@@ -69,6 +69,20 @@ __device__ inline float3 loadPosition(const uint8_t* vertices, uint32_t stride, 
     return make_float3(p[0], p[1], p[2]);
 }
 
+// ---- 0. input check ---------------------------------------------------------
+
+// Sets *flag when an index does not name a vertex.  The build reads vertices
+// through the indices, so a bad index has to be an error before it is a fault.
+__global__ __launch_bounds__(256) void indexCheckKernel(const uint32_t* indices, size_t count, uint32_t vertexCount,
+                                                        uint32_t* flag) {
+    bool bad = false;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        bad = bad || indices[i] >= vertexCount;
+    if (__ballot(bad) != 0ULL && (threadIdx.x & 63) == 0)
+        atomicOr(flag, 1U);
+}
+
 // ---- 1. triangle bounds + centroid extent ---------------------------------
 
 // centroidBounds: 6 ordered-bit words, lo.xyz then hi.xyz.
@@ -624,7 +638,6 @@ struct DeviceBuffer {
 
 rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
                     hipStream_t stream, rt_blas* blas) {
-    (void)vertexCount;
     hipEvent_t start, stop;
     RT_HIP(hipEventCreate(&start));
     RT_HIP(hipEventCreate(&stop));
@@ -659,6 +672,24 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_TRY(rootBox.allocate(sizeof(Box4)));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&blas->triangles), sizeof(PackedTriangle) * n));
 
+    {
+        // cbounds doubles as the flag of the index check before it takes the centroid bounds
+        RT_HIP(hipMemsetAsync(cbounds.data, 0, sizeof(uint32_t), stream));
+        const size_t count = 3 * static_cast<size_t>(n);
+        const unsigned grid = static_cast<unsigned>(std::min<size_t>(divUp(count, 256), 65536));
+        hipLaunchKernelGGL(indexCheckKernel, dim3(grid), dim3(256), 0, stream, indices, count, vertexCount,
+                           cbounds.as<uint32_t>());
+        uint32_t bad = 0;
+        RT_HIP(hipMemcpyAsync(&bad, cbounds.data, sizeof(bad), hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+        if (bad) {
+            (void)hipEventDestroy(start);
+            (void)hipEventDestroy(stop);
+            (void)hipFree(blas->triangles);
+            blas->triangles = nullptr;
+            return failInvalid("a triangle index is not below the vertex count");
+        }
+    }
     const uint32_t initBounds[6] = {0xffffffffU, 0xffffffffU, 0xffffffffU, 0U, 0U, 0U};
     RT_HIP(hipMemcpyAsync(cbounds.data, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream));
     const auto* vbytes = static_cast<const uint8_t*>(vertices);

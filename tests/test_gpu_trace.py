@@ -248,3 +248,19 @@ def test_empty_geometry_is_rejected(engine):
         engine.Blas(torch.zeros((3, 16), device="cuda"), torch.zeros((0, 3), dtype=torch.int32, device="cuda"))
     with pytest.raises(engine.EngineError):
         engine.Scene([])
+
+
+def test_index_beyond_the_vertices_is_rejected(engine):
+    """The build reads vertices through the indices; an index that names no vertex is an error message,
+    not a read outside the vertex buffer."""
+    import torch
+    scene = workloads.triangle_soup(5000, seed=2)
+    v = dev(scene["geometries"][0]["vertices"])
+    idx = scene["geometries"][0]["indices"].astype(np.int32).copy()
+    engine.Blas(v, dev(idx))
+    for bad in (len(scene["geometries"][0]["vertices"]), 0x7fffffff, -1):
+        broken = idx.copy()
+        broken[4321, 1] = bad
+        with pytest.raises(engine.EngineError, match="index"):
+            engine.Blas(v, dev(broken))
+    torch.cuda.synchronize()
