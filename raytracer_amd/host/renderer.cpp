@@ -183,6 +183,7 @@ struct Renderer::Impl {
                 "Export GLB instead");  // renderer.cpp:219-223
         if (renderWidth == 0 || renderHeight == 0)
             throw std::runtime_error("The image has no pixels");
+        checkReferences(scene);
         width = renderWidth;
         height = renderHeight;
         std::memset(&launch, 0, sizeof(launch));
@@ -207,6 +208,37 @@ struct Renderer::Impl {
         causticsEnabled = profile == Profile::Final;  // renderer.cpp:251
         configureCamera(scene.cameras.front());
         reset();
+    }
+
+    // Every index one table of the scene holds into another (instance -> geometry ->
+    // material -> texture -> image, triangle -> vertex) is checked here: the device
+    // code follows them without looking, and a bad one is better an exception than
+    // a read outside a buffer.  (The reference relies on its loader for this.)
+    static void checkReferences(const Scene& scene) {
+        auto fail = [](const std::string& what, const std::string& name) {
+            throw std::runtime_error(what + (name.empty() ? std::string() : " (" + name + ")"));
+        };
+        for (const auto& instance : scene.instances)
+            if (instance.geometry >= scene.geometries.size())
+                fail("An instance refers to a geometry the scene does not have", instance.name);
+        for (const auto& geometry : scene.geometries) {
+            if (geometry.material >= scene.materials.size())
+                fail("A geometry refers to a material the scene does not have", geometry.name);
+            if (geometry.indices.size() % 3 != 0)
+                fail("The index count of a geometry is not a multiple of three", geometry.name);
+            for (const std::uint32_t index : geometry.indices)
+                if (index >= geometry.vertices.size())
+                    fail("A triangle refers to a vertex its geometry does not have", geometry.name);
+        }
+        for (const auto& material : scene.materials)
+            for (const TextureRef* ref : {&material.baseColorTexture, &material.metallicRoughnessTexture,
+                                          &material.normalTexture, &material.emissiveTexture,
+                                          &material.transmissionTexture, &material.thicknessTexture})
+                if (ref->texture >= 0 && static_cast<std::size_t>(ref->texture) >= scene.textures.size())
+                    fail("A material refers to a texture the scene does not have", material.name);
+        for (const auto& texture : scene.textures)
+            if (texture.image < 0 || static_cast<std::size_t>(texture.image) >= scene.images.size())
+                fail("A texture refers to an image the scene does not have", texture.name);
     }
 
     void uploadMaterials(const Scene& scene) {  // renderer.cpp:256-262

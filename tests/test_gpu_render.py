@@ -166,6 +166,25 @@ def test_reference_error_behaviour(R):
     r = R.Renderer(scene, 8, 8)
     with pytest.raises(Exception, match="denois"):
         r.denoise()
+    # references from one table of the scene into another are checked before anything reaches the device
+    import copy
+    broken = copy.deepcopy(scene)
+    broken["instances"][0] = (99, broken["instances"][0][1])
+    with pytest.raises(Exception, match="geometry the scene does not have"):
+        R.Renderer(broken, 8, 8)
+    broken = copy.deepcopy(scene)
+    broken["geometries"][0]["material"] = 99
+    with pytest.raises(Exception, match="material the scene does not have"):
+        R.Renderer(broken, 8, 8)
+    broken = copy.deepcopy(scene)
+    broken["geometries"][0]["indices"] = broken["geometries"][0]["indices"].copy()
+    broken["geometries"][0]["indices"].reshape(-1)[1] = 1 << 20
+    with pytest.raises(Exception, match="vertex its geometry does not have"):
+        R.Renderer(broken, 8, 8)
+    broken = copy.deepcopy(scene)
+    broken["materials"][0] = dict(broken["materials"][0], baseColorTexture=dict(texture=3, texCoord=0))
+    with pytest.raises(Exception, match="texture the scene does not have"):
+        R.Renderer(broken, 8, 8)
 
 
 def test_set_camera_and_profile_reset_accumulation(R):
