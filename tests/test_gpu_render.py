@@ -257,6 +257,38 @@ def test_ray_share_does_not_change_the_image(R):
             r.set_ray_share(*bad)
 
 
+def test_light_lists_none_many_and_finite_ranges(R, oracle):
+    """The corners of light selection: a scene with no light at all (nothing to sample, no shadow ray;
+    what remains is the constant background seen through the open front of the box), and one with five lights of all three kinds, finite ranges that cut some of them
+    off before the walls, a spot cone whose inner and outer angles coincide, and a light of zero
+    intensity (it is still selected with its share of the probability and adds nothing)."""
+    dark = workloads.cornell_box()
+    dark["lights"] = []
+    r, host, gpu, cpu = render_both(R, oracle, dark, 64, 48, 2)
+    assert np.isfinite(gpu).all() and (gpu[:, 3] == 1.0).all()
+    assert close_fraction(gpu, cpu) > 0.99
+    assert r.statistics()["shadow_rays"] == 0
+
+    scene = workloads.cornell_box()
+    inf = float("inf")
+    scene["lights"] = [
+        dict(transform=workloads.translation(-0.6, 1.7, 0.4), color=(1.0, 0.3, 0.2), intensity=2.0,
+             range=1.2, innerCone=0.0, outerCone=0.7853982, type=2),
+        dict(transform=workloads.look_at([0.5, 1.9, 0.5], [0.3, 0.0, -0.2]), color=(0.2, 0.6, 1.0), intensity=30.0,
+             range=2.5, innerCone=0.3, outerCone=0.3, type=1),
+        dict(transform=workloads.look_at([0.0, 1.9, 0.9], [0.0, 0.0, -0.9]), color=(1.0, 1.0, 0.8), intensity=0.6,
+             range=inf, innerCone=0.0, outerCone=0.7853982, type=0),
+        dict(transform=workloads.translation(0.0, 1.0, 0.0), color=(1.0, 1.0, 1.0), intensity=0.0,
+             range=inf, innerCone=0.0, outerCone=0.7853982, type=2),
+        dict(transform=workloads.translation(0.7, 0.3, 0.7), color=(0.4, 1.0, 0.4), intensity=1.0,
+             range=0.05, innerCone=0.0, outerCone=0.7853982, type=2),
+    ]
+    r, host, gpu, cpu = render_both(R, oracle, scene, 96, 72, 4)
+    assert np.isfinite(gpu).all() and cpu[:, :3].mean() > 0.005
+    assert close_fraction(gpu, cpu, rel=2e-3) > 0.98
+    assert rel_rmse(gpu[:, :3], cpu[:, :3]) < 5e-2
+
+
 def test_scene_loaded_from_gltf_renders_the_same(R, tmp_path):
     """A scene that went through the glTF writer and rt::loadScene renders bit-identically to the scene
     built directly (PNG texture and Radiance environment included; the environment is compared after the
