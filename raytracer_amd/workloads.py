@@ -475,3 +475,65 @@ def textured_sky_scene():
     return dict(geometries=geos, instances=inst, materials=materials, lights=[], cameras=[camera],
                 images=[checker_image()], textures=[dict(image=0)],
                 environment=dict(pixels=sky_environment(), rotation=0.4, strength=1.2, exposure=-0.5))
+
+
+def material_map_scene(seed=11):
+    """Every texture slot of a material at once: a floor with colour, normal and metallic-roughness maps
+    (the normal map through the second texture coordinate set, clamped and mirrored wrap modes), an
+    emissive panel whose emission comes from a striped map, and a glass ball whose transmission and
+    thickness are modulated by maps; tangents and both coordinate sets are filled in."""
+    rng = np.random.default_rng(seed)
+    size = 32
+    y, x = np.mgrid[0:size, 0:size]
+    bumps = np.stack([128 + 80 * np.sin(x * 0.8), 128 + 80 * np.cos(y * 0.6), np.full_like(x, 230.0),
+                      np.full_like(x, 255.0)], -1)
+    normal_map = np.ascontiguousarray(np.clip(bumps, 0, 255).astype(np.uint8))
+    rough_metal = np.ascontiguousarray(rng.integers(20, 256, (size, size, 4), dtype=np.uint8))
+    stripes = np.zeros((size, size, 4), np.uint8)
+    stripes[:, (x[0] // 4) % 2 == 0] = (255, 180, 90, 255)
+    stripes[..., 3] = 255
+    fade = np.zeros((size, size, 4), np.uint8)
+    fade[..., 0] = (x * 255 // (size - 1)).astype(np.uint8)          # transmission reads red
+    fade[..., 1] = (255 - y * 200 // (size - 1)).astype(np.uint8)    # thickness reads green
+    fade[..., 2:] = 255
+    images = [checker_image(), normal_map, rough_metal, np.ascontiguousarray(stripes), np.ascontiguousarray(fade)]
+    textures = [dict(image=0, wrapU=33071, wrapV=33071), dict(image=1, wrapU=10497, wrapV=33648),
+                dict(image=2, wrapU=33648, wrapV=10497), dict(image=3), dict(image=4)]
+
+    floor = quad([-2, 0, -2], [-2, 0, 2], [2, 0, 2], [2, 0, -2])
+    floor[0][:, 8:12] = (0.0, 0.0, 1.0, 1.0)
+    floor[0][:, 12:14] = floor[0][:, 12:14] * 1.6 - 0.3         # runs past [0, 1]: the wrap modes matter
+    floor[0][:, 14:16] = floor[0][:, 12:14][:, ::-1] * 2.5
+    panel = quad([-0.8, 1.6, -1.2], [0.8, 1.6, -1.2], [0.8, 0.4, -1.2], [-0.8, 0.4, -1.2])
+    ball = icosphere(3)
+    p = ball[0][:, 0:3]
+    ball[0][:, 12] = np.arctan2(p[:, 2], p[:, 0]) / (2.0 * math.pi) + 0.5
+    ball[0][:, 13] = np.arccos(np.clip(p[:, 1], -1.0, 1.0)) / math.pi
+    ball[0][:, 14:16] = ball[0][:, 12:14] * 3.0
+    tangent = np.stack([-p[:, 2], np.zeros(len(p)), p[:, 0]], 1)
+    tangent /= np.maximum(np.linalg.norm(tangent, axis=1, keepdims=True), 1e-6)
+    ball[0][:, 8:11] = tangent
+    ball[0][:, 11] = -1.0
+
+    materials = [default_material(metallic=1.0),
+                 default_material(metallic=1.0, roughness=1.0,
+                                  baseColorTexture=dict(texture=0, scale=(1.0, 1.0)),
+                                  normalTexture=dict(texture=1, texCoord=1, strength=0.7, rotation=0.2),
+                                  metallicRoughnessTexture=dict(texture=2, offset=(0.25, -0.4), scale=(2.0, 3.0))),
+                 default_material(baseColor=(0.1, 0.1, 0.1, 1.0), emissive=(1.0, 1.0, 1.0), emissiveStrength=4.0,
+                                  emissiveTexture=dict(texture=3, scale=(2.0, 1.0))),
+                 default_material(baseColor=(0.95, 0.95, 1.0, 1.0), roughness=0.15, transmission=1.0, ior=1.5,
+                                  thickness=0.4, attenuationColor=(0.3, 0.8, 0.6), attenuationDistance=0.6,
+                                  transmissionTexture=dict(texture=4), thicknessTexture=dict(texture=4, texCoord=1),
+                                  normalTexture=dict(texture=1, scale=(2.0, 2.0), strength=0.4))]
+    geos = [{"vertices": floor[0], "indices": floor[1], "material": 1},
+            {"vertices": panel[0], "indices": panel[1], "material": 2},
+            {"vertices": ball[0], "indices": ball[1], "material": 3}]
+    inst = [(0, np.eye(4, dtype=np.float32).reshape(-1)), (1, np.eye(4, dtype=np.float32).reshape(-1)),
+            (2, rotation_y(0.7, 0.3, 0.55, 0.3, 0.55))]
+    lights = [dict(transform=translation(-0.8, 2.2, 1.2), color=(1.0, 0.95, 0.9), intensity=6.0,
+                   range=float("inf"), innerCone=0.0, outerCone=0.7853982, type=2)]
+    camera = dict(transform=look_at([0.2, 1.3, 3.2], [0.0, 0.5, 0.0]), verticalFov=0.62, aspectRatio=0.0,
+                  nearPlane=0.01, aperture=0.0, focusDistance=3.0)
+    return dict(geometries=geos, instances=inst, materials=materials, lights=lights, cameras=[camera],
+                images=images, textures=textures, environment=None)
