@@ -343,6 +343,16 @@ def test_scene_loaded_from_gltf_renders_the_same(R, tmp_path):
     assert np.array_equal(a.linear_pixels(), b.linear_pixels())
     assert a.linear_pixels()[..., :3].max() > 0.0
 
+    # every material map, the second coordinate set, tangents, texture transforms and sampler wrap modes
+    scene = workloads.material_map_scene()
+    for kind in ("glb", "gltf"):
+        path = write_scene(scene, tmp_path / f"maps.{kind}", kind)
+        a, b = R.Renderer(scene, 80, 56), R.Renderer(R.load_scene(path), 80, 56)
+        for _ in range(2):
+            a.render()
+            b.render()
+        assert np.array_equal(a.linear_pixels(), b.linear_pixels()), kind
+
 
 def test_command_line_renderer_writes_the_renderer_s_image(R, tmp_path):
     """raytracer scene.glb --output x.png / x.exr: the files hold what Renderer::pixels() /
