@@ -48,7 +48,9 @@ struct Buffers {
     float4* throughput;          // xyz + lastPdf (camera) / power xyz (photons)
     float4* lastOrigin;          // xyz + flags
     float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
-    uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length
+    float4* gather[4];           // photon queries a shade launch leaves for the gather launch behind it:
+                                 // point + path, normal, throughput, surface colour x kernel weight
+    uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length, [3] photon queries
     uint32_t* feed;              // ray-feed cursors of the trace launch (kFeedWords), zero between launches
     unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
                                  // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
         b.counts[0] = count;
         b.counts[1] = 0;
         b.counts[2] = 0;
+        b.counts[3] = 0;
     }
     if (i >= count)
         return;
@@ -296,7 +299,6 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     float shadowLimit = 0.0f;
     uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
     uint32_t path = 0;
-    uint32_t gathered = 0, gatherQueries = 0;
 
     if (active) {
         path = b.rayPath[which][slot];
@@ -388,17 +390,23 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
             }
             b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 
-            // caustic gather, device.cu:722-766, 949-950
+            // caustic gather, device.cu:722-766, 949-950: the query is left for causticGatherKernel,
+            // which walks the photon map with dense waves instead of the few lanes that want it here
             if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
-                float fx, fy, fz;
-                gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, hit.position.x,
-                           hit.position.y, hit.position.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered);
-                gatherQueries = 1;
+                const unsigned long long votes = __ballot(1);
+                const int lane = threadIdx.x & 63;
+                uint32_t base = 0;
+                if (lane == __ffsll(static_cast<long long>(votes)) - 1)
+                    base = atomicAdd(&b.counts[3], static_cast<uint32_t>(__popcll(votes)));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t query = base + __popcll(votes & ((1ULL << lane) - 1ULL));
                 const float radiusSquared = p.photonRadius * p.photonRadius;
                 const float kernel = 2.0f / (3.14159265f * radiusSquared * 3.14159265f);
-                const V3 caustic = rgb(m.baseColor) * (diffuseWeight * kernel) * V3{fx, fy, fz};
-                const V3 sum = rgb(b.sample[3][path]) + throughput * caustic;
-                b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+                const V3 weight = rgb(m.baseColor) * (diffuseWeight * kernel);
+                b.gather[0][query] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(path));
+                b.gather[1][query] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+                b.gather[2][query] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                b.gather[3][query] = make_float4(weight.x, weight.y, weight.z, 0.0f);
             }
 
             // scattering, device.cu:952-1032
@@ -471,8 +479,30 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
         b.shadowPath[shadowSlot] = path;
         b.shadowTarget[shadowSlot] = make_uint2(targetInstance, targetPrimitive);
     }
-    // gather statistics: one atomic pair per wave
-    unsigned long long q = gatherQueries, g = gathered;
+}
+
+// The photon queries of one shade launch (device.cu:722-766, 949-950): each adds its density
+// estimate to the caustic sum of its path.  A path has at most one query per bounce, so the
+// order of the queue does not enter any sum.
+__global__ __launch_bounds__(kShadeBlock, 8) void causticGatherKernel(rt_launch_params p, Buffers b) {
+    const uint32_t n = b.counts[3];
+    if (blockIdx.x * kShadeBlock >= n)
+        return;
+    const uint32_t query = blockIdx.x * kShadeBlock + threadIdx.x;
+    uint32_t gathered = 0;
+    if (query < n) {
+        const float4 point = b.gather[0][query];
+        const float4 normal = b.gather[1][query];
+        const uint32_t path = __float_as_uint(point.w);
+        float fx, fy, fz;
+        gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
+                   normal.x, normal.y, normal.z, fx, fy, fz, &gathered);
+        const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
+        const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
+        b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    }
+    // statistics: one atomic pair per wave
+    unsigned long long q = query < n ? 1ULL : 0ULL, g = gathered;
 #pragma unroll
     for (int delta = 32; delta >= 1; delta >>= 1) {
         q += __shfl_down(q, delta, 64);
@@ -494,6 +524,7 @@ __global__ void advanceKernel(Buffers b, int which) {
         b.stats[1] += b.counts[2];
         b.counts[which] = 0;
         b.counts[2] = 0;
+        b.counts[3] = 0;
     }
 }
 
@@ -788,6 +819,8 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     allocate(b.lastOrigin, maxPaths);
     for (int k = 0; k < 6; ++k)
         allocate(b.sample[k], maxPaths);
+    for (int k = 0; k < 4; ++k)
+        allocate(b.gather[k], maxPaths);
     allocate(b.counts, 4);
     allocate(b.feed, kFeedWords);
     allocate(b.stats, 8);
@@ -990,6 +1023,8 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
             StageTimer timer(w, s, 2);
             hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
+            if (params->photonRadius > 0.0f)
+                hipLaunchKernelGGL(causticGatherKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, b);
         }
         // the shadow rays of this bounce travel with the extend rays of the next
         trace(depth + 1 < params->maxDepth ? 1 - which : -1, 1);

@@ -86,6 +86,12 @@ def load():
         raise EngineError(
             f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback path")
+    # torch first: its wheel carries a HIP runtime of its own under the same library name, and a
+    # process that loads the system's copy before torch's finds no device from torch afterwards
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         try:
