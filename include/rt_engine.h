@@ -83,6 +83,21 @@ rt_status rt_photon_gather_counted(const rt_photon* sorted, const uint32_t* cell
                                    float radius, const float* qpos, const float* qnormal, uint32_t n, float* flux,
                                    uint64_t* visitedPhotons, void* stream);
 
+/* One bit per bucket of a built grid, set where the bucket holds photons:
+ * bucket b is bit (b & 31) of word (b >> 5); `bitmap` has
+ * max(1, bucketCount / 32) words.  No counterpart upstream (device.cu:729-762
+ * reads the range of every neighbour cell): a photon map much sparser than
+ * its table leaves most buckets empty, the bits of a 2^22-bucket table stay
+ * in the L2 cache where the table itself does not, and an empty bucket adds
+ * nothing to a sum, so a gather that asks the bit first returns the same
+ * floats. */
+rt_status rt_photon_bucket_bitmap(const uint32_t* cellStart, uint32_t bucketCount, uint32_t* bitmap, void* stream);
+
+/* rt_photon_gather that skips the buckets whose bit is clear. */
+rt_status rt_photon_gather_masked(const rt_photon* sorted, const uint32_t* cellStart, const uint32_t* bitmap,
+                                  uint32_t bucketCount, float radius, const float* qpos, const float* qnormal,
+                                  uint32_t n, float* flux, void* stream);
+
 /* ------------------------------------------------------------------------
  * Acceleration structures — replace the OptiX GAS / IAS builds of
  * src/renderer.cpp:343-396 and :398-434
@@ -225,6 +240,12 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
+/* Bucket bits (rt_photon_bucket_bitmap) of the photon grid the launch
+ * parameters of later rt_render_sample calls point at, or null (the default)
+ * to read every range.  The launch parameters keep the reference's layout
+ * (gpu_shared.hpp:95-145), which has no room for the pointer.  The caller
+ * keeps the bits in step with the grid. */
+rt_status rt_wavefront_set_bucket_bitmap(rt_wavefront* wavefront, const uint32_t* bitmap);
 /* Whether kernels put on these HIP streams (at most 16) really run side by
  * side: a process has a limited number of hardware queues, streams beyond
  * that number share one, and work on two streams of one queue runs in turn.

@@ -32,14 +32,24 @@ __device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float 
                         bucketCount);
 }
 
+#ifndef RT_GATHER_CHUNK
+#define RT_GATHER_CHUNK 8
+#endif
+constexpr uint32_t kGatherChunk = RT_GATHER_CHUNK;
+
 // Flux sum of one query in the reference's own order (cells z, y, x from -1 to
 // 1, a bucket reached twice counted once, photons in stored order), so the
 // float sums match a scalar evaluation bit for bit.  `visitedPhotons`, when not
 // null, receives the number of photons read (cells out of the sphere's reach
 // are not read, see below).
+// `occupied`, when not null, holds one bit per bucket, set where the bucket has
+// photons: with a map much sparser than its table most look-ups end at that bit
+// (the bits of a 2^22-bucket table are 512 KB and stay in the L2 cache, the
+// table's 16 MB do not), and an empty bucket adds nothing to any sum.
 __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
                                   float radius, float hx, float hy, float hz, float nx, float ny, float nz, float& fx,
-                                  float& fy, float& fz, uint32_t* visitedPhotons) {
+                                  float& fy, float& fz, uint32_t* visitedPhotons,
+                                  const uint32_t* occupied = nullptr) {
     const int cx = toInt(floorf(hx / radius));
     const int cy = toInt(floorf(hy / radius));
     const int cz = toInt(floorf(hz / radius));
@@ -116,21 +126,39 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
             bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
                          static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
                          static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+        if (occupied && !(occupied[bucket >> 5] >> (bucket & 31U) & 1U))
+            continue;
         const uint32_t begin = cellStart[bucket];
         const uint32_t end = cellStart[bucket + 1U];
         read += end - begin;
-#pragma unroll 2
-        for (uint32_t index = begin; index < end; ++index) {
-            const float* p = reinterpret_cast<const float*>(sorted + index);
-            const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
-            const float distanceSquared = ox * ox + oy * oy + oz * oz;
-            const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
-            if (distanceSquared >= radiusSquared || cosine < 0.7f)
-                continue;
-            const float weight = 1.0f - distanceSquared / radiusSquared;
-            fx = fx + p[3] * weight;
-            fy = fy + p[4] * weight;
-            fz = fz + p[5] * weight;
+        // kGatherChunk photons at a time: their positions are loaded together (the
+        // index is clamped into the range, so no load waits for a comparison), which
+        // keeps several loads in flight where a photon-by-photon loop has one; the
+        // rest of a photon is read only when it is within the radius, which few of a
+        // neighbour cell's are.  The sums still take the photons in index order.
+#pragma unroll 1
+        for (uint32_t index = begin; index < end; index += kGatherChunk) {
+            float distanceSquared[kGatherChunk];
+#pragma unroll
+            for (uint32_t k = 0; k < kGatherChunk; ++k) {
+                const uint32_t at = index + k < end ? index + k : end - 1U;
+                const float* p = reinterpret_cast<const float*>(sorted + at);
+                const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
+                distanceSquared[k] = ox * ox + oy * oy + oz * oz;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kGatherChunk; ++k) {
+                if (index + k >= end || distanceSquared[k] >= radiusSquared)
+                    continue;
+                const float* p = reinterpret_cast<const float*>(sorted + index + k);
+                const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
+                if (cosine < 0.7f)
+                    continue;
+                const float weight = 1.0f - distanceSquared[k] / radiusSquared;
+                fx = fx + p[3] * weight;
+                fy = fy + p[4] * weight;
+                fz = fz + p[5] * weight;
+            }
         }
     }
     if (visitedPhotons)

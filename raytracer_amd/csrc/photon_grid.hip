@@ -89,17 +89,29 @@ __global__ __launch_bounds__(256) void photonReorderKernel(const rt_photon* phot
     }
 }
 
+// One bit per bucket, set where the bucket holds photons (bucket b is bit b & 31 of word b >> 5).
+__global__ __launch_bounds__(256) void bucketBitmapKernel(const uint32_t* cellStart, uint32_t bucketCount,
+                                                          uint32_t* bitmap) {
+    const uint32_t bucket = blockIdx.x * 256U + threadIdx.x;
+    const bool holds = bucket < bucketCount && cellStart[bucket + 1U] != cellStart[bucket];
+    const unsigned long long votes = __ballot(holds);
+    const uint32_t half = threadIdx.x & 32U;  // lanes 0 and 32 of a wave write one word each
+    if ((threadIdx.x & 31U) == 0U && bucket < bucketCount)
+        bitmap[bucket >> 5] = static_cast<uint32_t>(votes >> half);
+}
+
 // One query per lane.
 __global__ __launch_bounds__(256, 8) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
                                                           uint32_t bucketCount, float radius, const float* qpos,
                                                           const float* qnormal, uint32_t n, float* flux,
-                                                          unsigned long long* visitedTotal) {
+                                                          unsigned long long* visitedTotal,
+                                                          const uint32_t* occupied) {
     const size_t q = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     uint32_t read = 0;
     if (q < n) {
         float fx, fy, fz;
         gatherFlux(sorted, cellStart, bucketCount, radius, qpos[3 * q], qpos[3 * q + 1], qpos[3 * q + 2], qnormal[3 * q],
-                   qnormal[3 * q + 1], qnormal[3 * q + 2], fx, fy, fz, visitedTotal ? &read : nullptr);
+                   qnormal[3 * q + 1], qnormal[3 * q + 2], fx, fy, fz, visitedTotal ? &read : nullptr, occupied);
         flux[3 * q] = fx;
         flux[3 * q + 1] = fy;
         flux[3 * q + 2] = fz;
@@ -270,7 +282,34 @@ rt_status rt_photon_gather(const rt_photon* sorted, const uint32_t* cellStart, u
         return rt::failInvalid("null pointer");
     hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
-                       flux, static_cast<unsigned long long*>(nullptr));
+                       flux, static_cast<unsigned long long*>(nullptr), static_cast<const uint32_t*>(nullptr));
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+rt_status rt_photon_bucket_bitmap(const uint32_t* cellStart, uint32_t bucketCount, uint32_t* bitmap, void* stream) {
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return rt::failInvalid("bucketCount must be a power of two");
+    if (!cellStart || !bitmap)
+        return rt::failInvalid("null pointer");
+    hipLaunchKernelGGL(rt::bucketBitmapKernel, dim3(rt::divUp(bucketCount, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), cellStart, bucketCount, bitmap);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
+rt_status rt_photon_gather_masked(const rt_photon* sorted, const uint32_t* cellStart, const uint32_t* bitmap,
+                                  uint32_t bucketCount, float radius, const float* qpos, const float* qnormal,
+                                  uint32_t n, float* flux, void* stream) {
+    if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
+        return rt::failInvalid("bucketCount must be a power of two");
+    if (n == 0)
+        return RT_SUCCESS;
+    if (!cellStart || !bitmap || !qpos || !qnormal || !flux)
+        return rt::failInvalid("null pointer");
+    hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
+                       flux, static_cast<unsigned long long*>(nullptr), bitmap);
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }
@@ -286,7 +325,8 @@ rt_status rt_photon_gather_counted(const rt_photon* sorted, const uint32_t* cell
         return rt::failInvalid("null pointer");
     hipLaunchKernelGGL(rt::photonGatherKernel, dim3(rt::divUp(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), sorted, cellStart, bucketCount, radius, qpos, qnormal, n,
-                       flux, reinterpret_cast<unsigned long long*>(visitedPhotons));
+                       flux, reinterpret_cast<unsigned long long*>(visitedPhotons),
+                       static_cast<const uint32_t*>(nullptr));
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }

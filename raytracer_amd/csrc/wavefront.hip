@@ -54,6 +54,7 @@ struct Buffers {
     uint32_t* feed;              // ray-feed cursors of the trace launch (kFeedWords), zero between launches
     unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
                                  // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
+    const uint32_t* bucketBits;  // one bit per bucket of the photon grid, or null
     rt_photon* photonTemp;       // photon pass: one slot per emission of the batch
     uint32_t* photonFlags;
 };
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void causticGatherKernel(rt_launch_
         const uint32_t path = __float_as_uint(point.w);
         float fx, fy, fz;
         gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
-                   normal.x, normal.y, normal.z, fx, fy, fz, &gathered);
+                   normal.x, normal.y, normal.z, fx, fy, fz, &gathered, b.bucketBits);
         const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
         const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
         b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
@@ -866,6 +867,13 @@ rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32
         return failInvalid("the share of a ray launch is a fraction in (0, 1]");
     w->shareNumerator = numerator;
     w->shareDenominator = denominator;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_bucket_bitmap(rt_wavefront* w, const uint32_t* bitmap) {
+    if (!w)
+        return failInvalid("null pointer");
+    w->buffers.bucketBits = bitmap;
     return RT_SUCCESS;
 }
 

@@ -61,6 +61,8 @@ SYMBOLS = {
     "rt_trace_any": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "rt_trace_closest_counted": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "rt_photon_gather_counted": (C.c_int, [_vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "rt_photon_bucket_bitmap": (C.c_int, [_vp, _u32, _vp, _vp]),
+    "rt_photon_gather_masked": (C.c_int, [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, _vp]),
     "rt_scene_set_geometry": (C.c_int, [_vp, _vp, _u32]),
     "rt_wavefront_create": (C.c_int, [_u32, C.POINTER(_vp)]),
     "rt_wavefront_destroy": (None, [_vp]),
@@ -70,6 +72,7 @@ SYMBOLS = {
     "rt_wavefront_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
     "rt_wavefront_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
+    "rt_wavefront_set_bucket_bitmap": (C.c_int, [_vp, _vp]),
     "rt_streams_run_concurrently": (C.c_int, [_vp, _u32, _vp]),
     "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
 }
@@ -151,6 +154,15 @@ class PhotonGrid:
         self.scratch_bytes = nbytes
         self.count = 0
         self.cell_size = 0.0
+        self.bitmap = None
+
+    def mark_buckets(self, stream=None):
+        """Builds the bit-per-bucket map of the grid as it stands (rt_photon_bucket_bitmap)."""
+        import torch
+        if self.bitmap is None:
+            self.bitmap = torch.empty(max(1, self.bucket_count // 32), dtype=torch.int32, device=self.offsets.device)
+        check(load().rt_photon_bucket_bitmap(_ptr(self.offsets), self.bucket_count, _ptr(self.bitmap), _stream(stream)))
+        return self.bitmap
 
     def build(self, photons, cell_size, stream=None, sync=False):
         """photons: (n, 9) float32 device tensor."""
@@ -168,15 +180,21 @@ class PhotonGrid:
         self.count = n
         self.cell_size = float(cell_size)
 
-    def gather(self, qpos, qnormal, radius=None, stream=None, out=None, visited=None):
-        """visited: optional (1,) int64 device tensor that receives the number of photons read."""
+    def gather(self, qpos, qnormal, radius=None, stream=None, out=None, visited=None, masked=False):
+        """visited: optional (1,) int64 device tensor that receives the number of photons read;
+        masked: ask the bucket bits (mark_buckets, called after the last build) before a range."""
         import torch
         assert qpos.is_cuda and qpos.dtype == torch.float32 and qpos.is_contiguous()
         assert qnormal.is_cuda and qnormal.dtype == torch.float32 and qnormal.is_contiguous()
         n = qpos.shape[0]
         flux = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=qpos.device)
         r = float(self.cell_size if radius is None else radius)
-        if visited is None:
+        if masked:
+            assert visited is None and self.bitmap is not None
+            check(load().rt_photon_gather_masked(_ptr(self.sorted), _ptr(self.offsets), _ptr(self.bitmap),
+                                                 self.bucket_count, r, _ptr(qpos), _ptr(qnormal), n, _ptr(flux),
+                                                 _stream(stream)))
+        elif visited is None:
             check(load().rt_photon_gather(_ptr(self.sorted), _ptr(self.offsets), self.bucket_count, r, _ptr(qpos),
                                           _ptr(qnormal), n, _ptr(flux), _stream(stream)))
         else:

@@ -477,10 +477,23 @@ struct Renderer::Impl {
         photonScan.resize(photonScanStorage(launch.photonBucketCount));
         // until the first build every bucket is empty
         hipCheck(hipMemset(photonCellStart.data(), 0, counterBytes));
+        // one bit per bucket, set where the bucket holds photons: the gather asks it before a range
+        const std::size_t bitBytes = std::max<std::size_t>(1, launch.photonBucketCount / 32U) * sizeof(std::uint32_t);
+        photonBucketBits.resize(bitBytes);
+        hipCheck(hipMemset(photonBucketBits.data(), 0, bitBytes));
+        bindBucketBits();
         launch.photons = static_cast<rt_photon*>(photons.data());
         launch.photonCount = static_cast<std::uint32_t*>(photonCounter.data());
         launch.sortedPhotons = static_cast<const rt_photon*>(sortedPhotons.data());
         launch.photonCellStart = static_cast<const std::uint32_t*>(photonCellStart.data());
+    }
+
+    void bindBucketBits() {
+        for (auto& t : tiles)
+            if (t.wavefront)
+                engineCheck(rt_wavefront_set_bucket_bitmap(
+                                t.wavefront, static_cast<const std::uint32_t*>(photonBucketBits.data())),
+                            "rt_wavefront_set_bucket_bitmap");
     }
 
     void createBindingTable() {  // renderer.cpp:633-670: one record per geometry
@@ -575,6 +588,10 @@ struct Renderer::Impl {
             static_cast<std::uint32_t*>(photonCellCounts.data()), static_cast<std::uint32_t*>(photonCellStart.data()),
             photonScan.data(), photonScan.size(), static_cast<Photon*>(sortedPhotons.data()));
         engineCheck(status, "buildPhotonGrid");
+        engineCheck(rt_photon_bucket_bitmap(static_cast<const std::uint32_t*>(photonCellStart.data()),
+                                            launch.photonBucketCount,
+                                            static_cast<std::uint32_t*>(photonBucketBits.data()), nullptr),
+                    "rt_photon_bucket_bitmap");
         ++launch.photonPass;
         photonPassPending = false;
     }
@@ -665,6 +682,7 @@ struct Renderer::Impl {
             if (count > 1)
                 engineCheck(rt_wavefront_set_ray_share(t.wavefront, 1, 2), "rt_wavefront_set_ray_share");
         }
+        bindBucketBits();
     }
 
     // One stream per tile, chosen so that they run side by side.  A process has a
@@ -704,7 +722,7 @@ struct Renderer::Impl {
     Buffer materials, textures, lights, environment, environmentCdf;
     Buffer aov[7];  // accumulation, diffuse, reflection, refraction, caustics, albedo guide, normal guide
     Buffer output;
-    Buffer photons, sortedPhotons, photonCellCounts, photonCellStart, photonCounter, photonScan;
+    Buffer photons, sortedPhotons, photonCellCounts, photonCellStart, photonCounter, photonScan, photonBucketBits;
     rt_launch_params launch;
     float environmentPower = 0.0f;
     float causticRadius = 0.0f;

@@ -73,6 +73,30 @@ def test_gather_bit_exact(engine, oracle):
     assert (flux != 0).any()
 
 
+@pytest.mark.parametrize("n, B", [(20000, 1 << 20), (3000, 2), (500, 32), (40000, 1 << 12)])
+def test_bucket_bits_and_masked_gather(engine, oracle, n, B):
+    """The bit-per-bucket map marks exactly the buckets with photons, and a gather that asks the bit
+    before a range returns the floats of the plain gather (sparse table, two buckets where every cell
+    collides, a table of one word, a table fuller than its photon count)."""
+    r = 0.004
+    ph = workloads.caustic_photons(n, seed=5, extent=0.3)
+    grid = engine.PhotonGrid(n, B)
+    grid.build(dev(ph), r, sync=True)
+    bits = u32(grid.mark_buckets())
+    offsets = u32(grid.offsets).astype(np.int64)
+    holds = np.diff(offsets) > 0
+    want = np.zeros(max(1, B // 32) * 32, dtype=bool)
+    want[:B] = holds
+    got = ((bits[:, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(-1)
+    assert np.array_equal(got, want)
+    qp, qn = workloads.gather_queries(20000, seed=6, extent=0.3)
+    qp[:min(n, 2000)] = ph[:2000, :3]
+    plain = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+    masked = grid.gather(dev(qp), dev(qn), masked=True).cpu().numpy()
+    assert np.array_equal(plain.view(np.uint32), masked.view(np.uint32))
+    assert (plain != 0).any()
+
+
 def test_gather_collisions(engine, oracle):
     # two buckets: nearly every neighbour cell repeats a bucket
     ph = workloads.caustic_photons(3000, seed=2, extent=0.01)
