@@ -228,9 +228,11 @@ rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* para
  * Synchronises `stream`; reset != 0 zeroes the counters afterwards. */
 rt_status rt_wavefront_stats(rt_wavefront* wavefront, uint64_t* out8, int reset, void* stream);
 
-/* Measurement switches (both off by default). */
+/* Measurement switches (all off by default). */
 #define RT_WAVEFRONT_TIME_STAGES 1u      /* bracket every stage launch of rt_render_sample with HIP events */
 #define RT_WAVEFRONT_COUNT_TRAVERSAL 2u  /* ray launches count visited nodes / tested triangles */
+#define RT_WAVEFRONT_GATHER_PER_LANE 4u   /* photon queries that read many photons stay in the lane that drew them
+                                          * instead of going to a wave each: the same floats, for comparison */
 rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
 /* Share of the GPU's wave slots a ray launch of this state occupies, as
  * numerator / denominator of the resident set (default 1/1).  The ray stage

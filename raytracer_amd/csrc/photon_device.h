@@ -46,18 +46,22 @@ constexpr uint32_t kGatherChunk = RT_GATHER_CHUNK;
 // photons: with a map much sparser than its table most look-ups end at that bit
 // (the bits of a 2^22-bucket table are 512 KB and stay in the L2 cache, the
 // table's 16 MB do not), and an empty bucket adds nothing to any sum.
-__device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+// `budget`: the walk gives up (returns false, sums and count unusable) before it
+// reads a range that takes the photons read past this number; the caller hands
+// such a query to gatherFluxWave.
+__device__ inline bool gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
                                   float radius, float hx, float hy, float hz, float nx, float ny, float nz, float& fx,
                                   float& fy, float& fz, uint32_t* visitedPhotons,
-                                  const uint32_t* occupied = nullptr) {
-    const int cx = toInt(floorf(hx / radius));
-    const int cy = toInt(floorf(hy / radius));
-    const int cz = toInt(floorf(hz / radius));
+                                  const uint32_t* occupied = nullptr, uint32_t budget = 0xffffffffU);
+
+// The cell of a query and the neighbour cells (bit c of the result, c = x + 3 y + 9 z
+// with offsets 0..2) a gather does not read.
+__device__ inline uint32_t gatherPlan(uint32_t bucketCount, float radius, float hx, float hy, float hz, int& cx, int& cy,
+                                      int& cz) {
+    cx = toInt(floorf(hx / radius));
+    cy = toInt(floorf(hy / radius));
+    cz = toInt(floorf(hz / radius));
     const float radiusSquared = radius * radius;
-    fx = 0.0f;
-    fy = 0.0f;
-    fz = 0.0f;
-    uint32_t read = 0;
     uint32_t visited[27];
 #pragma unroll
     for (int c = 0; c < 27; ++c) {
@@ -114,6 +118,20 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
         if (outOfReach && !(repeatedLater >> c & 1U))
             skip |= 1U << c;
     }
+    return skip;
+}
+
+__device__ inline bool gatherFlux(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+                                  float radius, float hx, float hy, float hz, float nx, float ny, float nz, float& fx,
+                                  float& fy, float& fz, uint32_t* visitedPhotons, const uint32_t* occupied,
+                                  uint32_t budget) {
+    int cx, cy, cz;
+    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz);
+    const float radiusSquared = radius * radius;
+    fx = 0.0f;
+    fy = 0.0f;
+    fz = 0.0f;
+    uint32_t read = 0;
     // the walk itself is a plain loop (the bucket of cell c is hashed again
     // rather than kept): unrolled 27 times the compiler hoists all the range
     // loads and the kernel's register use quadruples
@@ -131,6 +149,8 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
         const uint32_t begin = cellStart[bucket];
         const uint32_t end = cellStart[bucket + 1U];
         read += end - begin;
+        if (read > budget)
+            return false;
         // kGatherChunk photons at a time: their positions are loaded together (the
         // index is clamped into the range, so no load waits for a comparison), which
         // keeps several loads in flight where a photon-by-photon loop has one; the
@@ -163,6 +183,69 @@ __device__ inline void gatherFlux(const rt_photon* sorted, const uint32_t* cellS
     }
     if (visitedPhotons)
         *visitedPhotons = read;
+    return true;
+}
+
+// gatherFlux for one query by a whole wave (every lane passes the same query and
+// gets the same result): the lanes test 64 photons of a range at a time, and
+// the photons inside the radius are then added in index order, as a single lane
+// would add them - a long range costs one coalesced load per 64 photons instead
+// of a chain of dependent loads in one lane.
+__device__ inline void gatherFluxWave(const rt_photon* sorted, const uint32_t* cellStart, uint32_t bucketCount,
+                                      float radius, float hx, float hy, float hz, float nx, float ny, float nz,
+                                      float& fx, float& fy, float& fz, uint32_t& visitedPhotons,
+                                      const uint32_t* occupied) {
+    int cx, cy, cz;
+    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz);
+    const float radiusSquared = radius * radius;
+    const uint32_t lane = threadIdx.x & 63U;
+    fx = 0.0f;
+    fy = 0.0f;
+    fz = 0.0f;
+    uint32_t read = 0;
+#pragma unroll 1
+    for (int c = 0; c < 27; ++c) {
+        if (skip >> c & 1U)
+            continue;
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const uint32_t bucket =
+            bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
+                         static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
+                         static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
+        if (occupied && !(occupied[bucket >> 5] >> (bucket & 31U) & 1U))
+            continue;
+        const uint32_t begin = cellStart[bucket];
+        const uint32_t end = cellStart[bucket + 1U];
+        read += end - begin;
+#pragma unroll 1
+        for (uint32_t base = begin; base < end; base += 64U) {
+            const uint32_t index = base + lane;
+            bool inside = false;
+            float px = 0.0f, py = 0.0f, pz = 0.0f;
+            if (index < end) {
+                const float* p = reinterpret_cast<const float*>(sorted + index);
+                const float ox = p[0] - hx, oy = p[1] - hy, oz = p[2] - hz;
+                const float distanceSquared = ox * ox + oy * oy + oz * oz;
+                const float cosine = p[6] * nx + p[7] * ny + p[8] * nz;
+                if (!(distanceSquared >= radiusSquared || cosine < 0.7f)) {
+                    const float weight = 1.0f - distanceSquared / radiusSquared;
+                    px = p[3] * weight;
+                    py = p[4] * weight;
+                    pz = p[5] * weight;
+                    inside = true;
+                }
+            }
+            unsigned long long votes = __ballot(inside);
+            while (votes) {
+                const int from = __ffsll(static_cast<long long>(votes)) - 1;
+                votes &= votes - 1ULL;
+                fx = fx + __shfl(px, from, 64);
+                fy = fy + __shfl(py, from, 64);
+                fz = fz + __shfl(pz, from, 64);
+            }
+        }
+    }
+    visitedPhotons = read;
 }
 
 }  // namespace rt

@@ -50,7 +50,10 @@ struct Buffers {
     float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
     float4* gather[4];           // photon queries a shade launch leaves for the gather launch behind it:
                                  // point + path, normal, throughput, surface colour x kernel weight
-    uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length, [3] photon queries
+    uint32_t* heavyQueries;      // photon queries that read more photons than one lane should walk
+    uint32_t heavyBudget;        // ... this many (kHeavyPhotons, or no limit when the hand-over is switched off)
+    uint32_t* counts;            // [0], [1] queue lengths, [2] shadow queue length, [3] photon queries,
+                                 // [4] heavy photon queries
     uint32_t* feed;              // ray-feed cursors of the trace launch (kFeedWords), zero between launches
     unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
                                  // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
         b.counts[1] = 0;
         b.counts[2] = 0;
         b.counts[3] = 0;
+        b.counts[4] = 0;
     }
     if (i >= count)
         return;
@@ -482,28 +486,46 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     }
 }
 
+// A query that would read more photons than this is taken out of the lane that
+// drew it: alone in its wave it is a chain of dependent loads that the whole
+// launch ends up waiting for.
+constexpr uint32_t kHeavyPhotons = 512;
+constexpr unsigned kHeavyGatherBlocks = 512;
+
 // The photon queries of one shade launch (device.cu:722-766, 949-950): each adds its density
 // estimate to the caustic sum of its path.  A path has at most one query per bounce, so the
-// order of the queue does not enter any sum.
+// order of the queue does not enter any sum.  Queries over the photon budget go on to
+// causticGatherHeavyKernel.
 __global__ __launch_bounds__(kShadeBlock, 8) void causticGatherKernel(rt_launch_params p, Buffers b) {
     const uint32_t n = b.counts[3];
     if (blockIdx.x * kShadeBlock >= n)
         return;
     const uint32_t query = blockIdx.x * kShadeBlock + threadIdx.x;
     uint32_t gathered = 0;
+    bool finished = false;
     if (query < n) {
         const float4 point = b.gather[0][query];
         const float4 normal = b.gather[1][query];
-        const uint32_t path = __float_as_uint(point.w);
         float fx, fy, fz;
-        gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
-                   normal.x, normal.y, normal.z, fx, fy, fz, &gathered, b.bucketBits);
-        const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
-        const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
-        b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        finished = gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y,
+                              point.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered, b.bucketBits, b.heavyBudget);
+        if (finished) {
+            const uint32_t path = __float_as_uint(point.w);
+            const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
+            const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
+            b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        } else {
+            const unsigned long long votes = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            uint32_t base = 0;
+            if (lane == __ffsll(static_cast<long long>(votes)) - 1)
+                base = atomicAdd(&b.counts[4], static_cast<uint32_t>(__popcll(votes)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            b.heavyQueries[base + __popcll(votes & ((1ULL << lane) - 1ULL))] = query;
+        }
     }
     // statistics: one atomic pair per wave
-    unsigned long long q = query < n ? 1ULL : 0ULL, g = gathered;
+    unsigned long long q = finished ? 1ULL : 0ULL, g = finished ? gathered : 0U;
 #pragma unroll
     for (int delta = 32; delta >= 1; delta >>= 1) {
         q += __shfl_down(q, delta, 64);
@@ -512,6 +534,31 @@ __global__ __launch_bounds__(kShadeBlock, 8) void causticGatherKernel(rt_launch_
     if ((threadIdx.x & 63) == 0 && q) {
         atomicAdd(&b.stats[2], q);
         atomicAdd(&b.stats[3], g);
+    }
+}
+
+// The queries causticGatherKernel passed on, one per wave (gatherFluxWave); the waves of the
+// launch take them in turn.
+__global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launch_params p, Buffers b) {
+    const uint32_t n = b.counts[4];
+    const uint32_t waves = gridDim.x * (kShadeBlock / 64);
+    const uint32_t lane = threadIdx.x & 63U;
+    for (uint32_t item = blockIdx.x * (kShadeBlock / 64) + (threadIdx.x >> 6); item < n; item += waves) {
+        const uint32_t query = b.heavyQueries[item];
+        const float4 point = b.gather[0][query];
+        const float4 normal = b.gather[1][query];
+        float fx, fy, fz;
+        uint32_t gathered = 0;
+        gatherFluxWave(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
+                       normal.x, normal.y, normal.z, fx, fy, fz, gathered, b.bucketBits);
+        if (lane == 0U) {
+            const uint32_t path = __float_as_uint(point.w);
+            const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
+            const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
+            b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+            atomicAdd(&b.stats[2], 1ULL);
+            atomicAdd(&b.stats[3], static_cast<unsigned long long>(gathered));
+        }
     }
 }
 
@@ -526,6 +573,7 @@ __global__ void advanceKernel(Buffers b, int which) {
         b.counts[which] = 0;
         b.counts[2] = 0;
         b.counts[3] = 0;
+        b.counts[4] = 0;
     }
 }
 
@@ -822,7 +870,9 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
         allocate(b.sample[k], maxPaths);
     for (int k = 0; k < 4; ++k)
         allocate(b.gather[k], maxPaths);
-    allocate(b.counts, 4);
+    allocate(b.heavyQueries, maxPaths);
+    b.heavyBudget = kHeavyPhotons;
+    allocate(b.counts, 8);
     allocate(b.feed, kFeedWords);
     allocate(b.stats, 8);
     allocate(b.photonTemp, maxPaths);
@@ -830,7 +880,7 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     allocate(w->scanCounts, static_cast<size_t>(maxPaths) + 1);
     allocate(w->scanPartials, scanScratchEntries(static_cast<size_t>(maxPaths) + 1));
     if (status == RT_SUCCESS) {
-        if (hipMemset(b.counts, 0, sizeof(uint32_t) * 4) != hipSuccess ||
+        if (hipMemset(b.counts, 0, sizeof(uint32_t) * 8) != hipSuccess ||
             hipMemset(b.stats, 0, sizeof(unsigned long long) * 8) != hipSuccess)
             status = failInvalid("hipMemset (wavefront counters)");
     }
@@ -857,6 +907,7 @@ rt_status rt_wavefront_configure(rt_wavefront* w, uint32_t flags) {
     if (!w)
         return failInvalid("null pointer");
     w->flags = flags;
+    w->buffers.heavyBudget = flags & RT_WAVEFRONT_GATHER_PER_LANE ? 0xffffffffU : kHeavyPhotons;
     return RT_SUCCESS;
 }
 
@@ -1031,8 +1082,12 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
             StageTimer timer(w, s, 2);
             hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
-            if (params->photonRadius > 0.0f)
+            if (params->photonRadius > 0.0f) {
                 hipLaunchKernelGGL(causticGatherKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, b);
+                if (b.heavyBudget != 0xffffffffU)
+                    hipLaunchKernelGGL(causticGatherHeavyKernel, dim3(std::min(blocks, kHeavyGatherBlocks)),
+                                       dim3(kShadeBlock), 0, s, *params, b);
+            }
         }
         // the shadow rays of this bounce travel with the extend rays of the next
         trace(depth + 1 < params->maxDepth ? 1 - which : -1, 1);
@@ -1061,7 +1116,7 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
         const unsigned blocks = divUp(count, kShadeBlock);
         const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
         const uint2 limits = limitsOf(scene);
-        RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 4, s));
+        RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 8, s));
         RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
         hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, firstEmission + done,
                            count, b);

@@ -421,8 +421,8 @@ void* rth_renderer_accumulation_buffer(rt::Renderer* r, int index) {
     return p;
 }
 int rth_renderer_statistics(rt::Renderer* r, uint64_t* out8) { return guarded([&] { r->statistics(out8); }); }
-int rth_renderer_set_measurement(rt::Renderer* r, int timeStages, int countTraversal) {
-    return guarded([&] { r->setMeasurement(timeStages != 0, countTraversal != 0); });
+int rth_renderer_set_measurement(rt::Renderer* r, int timeStages, int countTraversal, int gatherPerLane) {
+    return guarded([&] { r->setMeasurement(timeStages != 0, countTraversal != 0, gatherPerLane != 0); });
 }
 int rth_renderer_stage_timings(rt::Renderer* r, float* milliseconds5, uint32_t* launches5) {
     return guarded([&] { r->stageTimings(milliseconds5, launches5); });

@@ -830,9 +830,10 @@ void Renderer::statistics(std::uint64_t out[8]) {
             out[k] += part[k];
     }
 }
-void Renderer::setMeasurement(bool timeStages, bool countTraversal) {
-    impl_->measurementFlags =
-        (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) | (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U);
+void Renderer::setMeasurement(bool timeStages, bool countTraversal, bool gatherPerLane) {
+    impl_->measurementFlags = (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) |
+                              (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U) |
+                              (gatherPerLane ? RT_WAVEFRONT_GATHER_PER_LANE : 0U);
     for (auto& t : impl_->tiles)
         engineCheck(rt_wavefront_configure(t.wavefront, impl_->measurementFlags), "rt_wavefront_configure");
 }

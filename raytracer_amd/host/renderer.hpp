@@ -75,8 +75,9 @@ public:
     // tested, [6] instances entered (the last three only while traversal counting
     // is on).  Waits for the GPU.
     void statistics(std::uint64_t out[8]);
-    // Measurement switches: event-time every stage launch / count traversal steps.
-    void setMeasurement(bool timeStages, bool countTraversal);
+    // Measurement switches: event-time every stage launch / count traversal steps /
+    // keep every photon query in the lane that drew it (same image, for comparison).
+    void setMeasurement(bool timeStages, bool countTraversal, bool gatherPerLane = false);
     // Event-timed milliseconds and launch counts per stage since the last call:
     // generate, trace, shade, queue bookkeeping, accumulate.  Waits for the GPU.
     void stageTimings(float milliseconds[5], std::uint32_t launches[5]);

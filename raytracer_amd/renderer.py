@@ -125,7 +125,7 @@ _SIG = {
     "rth_renderer_finish_photon_pass": (C.c_int, [_vp, _u32]),
     "rth_renderer_accumulation_buffer": (_vp, [_vp, C.c_int]),
     "rth_renderer_statistics": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
-    "rth_renderer_set_measurement": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rth_renderer_set_measurement": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "rth_renderer_stage_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "rth_renderer_synchronize": (C.c_int, [_vp]),
     "rth_renderer_launch_params": (None, [_vp, C.POINTER(LaunchParams)]),
@@ -446,8 +446,9 @@ class Renderer:
         return dict(extend_rays=out[0], shadow_rays=out[1], gather_queries=out[2], gathered_photons=out[3],
                     nodes=out[4], triangles=out[5], instances=out[6], refused_references=out[7])
 
-    def set_measurement(self, time_stages=False, count_traversal=False):
-        _check(load().rth_renderer_set_measurement(self.handle, int(time_stages), int(count_traversal)))
+    def set_measurement(self, time_stages=False, count_traversal=False, gather_per_lane=False):
+        _check(load().rth_renderer_set_measurement(self.handle, int(time_stages), int(count_traversal),
+                                                   int(gather_per_lane)))
 
     def stage_timings(self):
         """{stage: (milliseconds, launches)} of the event-timed launches since the last call."""
