@@ -489,7 +489,10 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
 // A query that would read more photons than this is taken out of the lane that
 // drew it: alone in its wave it is a chain of dependent loads that the whole
 // launch ends up waiting for.
-constexpr uint32_t kHeavyPhotons = 512;
+#ifndef RT_GATHER_HEAVY
+#define RT_GATHER_HEAVY 256
+#endif
+constexpr uint32_t kHeavyPhotons = RT_GATHER_HEAVY;
 constexpr unsigned kHeavyGatherBlocks = 512;
 
 // The photon queries of one shade launch (device.cu:722-766, 949-950): each adds its density
