@@ -57,7 +57,7 @@ __device__ inline bool gatherFlux(const rt_photon* sorted, const uint32_t* cellS
 // The cell of a query and the neighbour cells (bit c of the result, c = x + 3 y + 9 z
 // with offsets 0..2) a gather does not read.
 __device__ inline uint32_t gatherPlan(uint32_t bucketCount, float radius, float hx, float hy, float hz, int& cx, int& cy,
-                                      int& cz) {
+                                      int& cz, const uint32_t* occupied) {
     cx = toInt(floorf(hx / radius));
     cy = toInt(floorf(hy / radius));
     cz = toInt(floorf(hz / radius));
@@ -118,6 +118,21 @@ __device__ inline uint32_t gatherPlan(uint32_t bucketCount, float radius, float 
         if (outOfReach && !(repeatedLater >> c & 1U))
             skip |= 1U << c;
     }
+    // the bucket bits of the cells that are left, nine independent loads at a time
+    // (a cell already out of the walk reads word 0)
+    if (occupied) {
+#pragma unroll
+        for (int group = 0; group < 27; group += 9) {
+            uint32_t words[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                words[k] = occupied[skip >> (group + k) & 1U ? 0U : visited[group + k] >> 5];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (!(words[k] >> (visited[group + k] & 31U) & 1U))
+                    skip |= 1U << (group + k);
+        }
+    }
     return skip;
 }
 
@@ -126,26 +141,38 @@ __device__ inline bool gatherFlux(const rt_photon* sorted, const uint32_t* cellS
                                   float& fy, float& fz, uint32_t* visitedPhotons, const uint32_t* occupied,
                                   uint32_t budget) {
     int cx, cy, cz;
-    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz);
+    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz, occupied);
     const float radiusSquared = radius * radius;
     fx = 0.0f;
     fy = 0.0f;
     fz = 0.0f;
     uint32_t read = 0;
-    // the walk itself is a plain loop (the bucket of cell c is hashed again
+    // The walk itself is a plain loop (the bucket of cell c is hashed again
     // rather than kept): unrolled 27 times the compiler hoists all the range
-    // loads and the kernel's register use quadruples
+    // loads and the kernel's register use quadruples.  Without bucket bits every
+    // lane steps through the 27 cells together.  With them each lane goes from
+    // one of its occupied cells to its next: in a sparse map a lane has one or two
+    // of them, not the same ones as its neighbours, and a wave that stepped
+    // through all 27 would wait out a chain of dependent loads at nearly every
+    // one for the sake of a few lanes; lanes that share their cells (a dense map,
+    // neighbouring queries) still move together.
+    uint32_t todo = ~skip & 0x7ffffffU;
 #pragma unroll 1
-    for (int c = 0; c < 27; ++c) {
-        if (skip >> c & 1U)
+    for (int step = 0; step < 27; ++step) {
+        int c = step;
+        if (occupied) {
+            if (todo == 0U)
+                break;
+            c = __ffs(static_cast<int>(todo)) - 1;
+            todo &= todo - 1U;
+        } else if (skip >> c & 1U) {
             continue;
+        }
         const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
         const uint32_t bucket =
             bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
                          static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
                          static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
-        if (occupied && !(occupied[bucket >> 5] >> (bucket & 31U) & 1U))
-            continue;
         const uint32_t begin = cellStart[bucket];
         const uint32_t end = cellStart[bucket + 1U];
         read += end - begin;
@@ -196,7 +223,7 @@ __device__ inline void gatherFluxWave(const rt_photon* sorted, const uint32_t* c
                                       float& fx, float& fy, float& fz, uint32_t& visitedPhotons,
                                       const uint32_t* occupied) {
     int cx, cy, cz;
-    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz);
+    const uint32_t skip = gatherPlan(bucketCount, radius, hx, hy, hz, cx, cy, cz, occupied);
     const float radiusSquared = radius * radius;
     const uint32_t lane = threadIdx.x & 63U;
     fx = 0.0f;
@@ -212,8 +239,6 @@ __device__ inline void gatherFluxWave(const rt_photon* sorted, const uint32_t* c
             bucketOfCell(static_cast<int>(static_cast<uint32_t>(cx) + static_cast<uint32_t>(dx)),
                          static_cast<int>(static_cast<uint32_t>(cy) + static_cast<uint32_t>(dy)),
                          static_cast<int>(static_cast<uint32_t>(cz) + static_cast<uint32_t>(dz)), bucketCount);
-        if (occupied && !(occupied[bucket >> 5] >> (bucket & 31U) & 1U))
-            continue;
         const uint32_t begin = cellStart[bucket];
         const uint32_t end = cellStart[bucket + 1U];
         read += end - begin;
