@@ -146,6 +146,11 @@ def test_hostile_photons_and_queries(engine, oracle):
         both_nan = np.isnan(flux) & np.isnan(ref)
         assert np.array_equal(np.where(both_nan, 0, flux.view(np.uint32)), np.where(both_nan, 0, ref.view(np.uint32))), r
         assert both_nan.any() and (~both_nan).any()
+        # the walk over the occupied cells (bucket bits) on the same inputs
+        grid.mark_buckets()
+        masked = grid.gather(dev(qp), dev(qn), masked=True).cpu().numpy()
+        both_nan = np.isnan(masked) & np.isnan(ref)
+        assert np.array_equal(np.where(both_nan, 0, masked.view(np.uint32)), np.where(both_nan, 0, ref.view(np.uint32))), r
 
 
 def test_full_size_properties(engine, oracle):
