@@ -1045,6 +1045,11 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     RT_TRY(checkLaunch(w, params, scene));
     if (pixelEnd < pixelBegin || pixelEnd > params->width * params->height)
         return failInvalid("pixel range");
+    // a positive photon radius switches the caustic gather on; it reads these
+    if (params->photonRadius > 0.0f &&
+        (!params->sortedPhotons || !params->photonCellStart || params->photonBucketCount == 0 ||
+         (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
+        return failInvalid("photon radius set without a photon grid (sorted photons, cell starts, power-of-two bucket count)");
     const uint32_t count = pixelEnd - pixelBegin;
     if (count == 0)
         return RT_SUCCESS;

@@ -179,6 +179,41 @@ def test_heavy_photon_queries_give_the_same_floats(R, oracle):
     assert caustic[:, :3].sum() > 0 and np.isfinite(caustic).all()
 
 
+def test_sample_launch_through_the_c_abi(R, engine):
+    """rt_render_sample called directly on a wavefront state of the caller's own, with the launch
+    parameters of a Renderer: without bucket bits the gather reads every range (the 27-step walk, heavy
+    queries included) and the sample is the one the Renderer adds itself; launch parameters that switch
+    the gather on without a photon grid are refused before anything is launched."""
+    import ctypes as C
+    w, h = 48, 27
+    r = R.Renderer(workloads.caustic_lab(), w, h, 1)
+    r.set_photon_budget(1 << 21, 1 << 20, 1 << 14)
+    r.set_concurrent_tiles(1)
+    r.render()                     # photon pass 0 and sample 0
+    r.synchronize()
+    first = [R.device_to_host(r.accumulation_buffer(k), w * h * 16).copy() for k in range(7)]
+    lib = engine.load()
+    state = C.c_void_p(0)
+    engine.check(lib.rt_wavefront_create(w * h, C.byref(state)))
+    try:
+        params = r.launch_params()   # sample index 0 again: the running mean of x and x is x
+        params.sample = 0
+        engine.check(lib.rt_render_sample(state, C.byref(params), 0, w * h, None))
+        import torch
+        torch.cuda.synchronize()
+        again = [R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]
+        for k in range(7):
+            assert np.array_equal(first[k], again[k]), k
+        for field, value in (("sortedPhotons", None), ("photonCellStart", None), ("photonBucketCount", 0),
+                             ("photonBucketCount", 1000)):
+            broken = R.LaunchParams.from_buffer_copy(params)
+            setattr(broken, field, value)
+            with pytest.raises(engine.EngineError, match="photon grid"):
+                engine.check(lib.rt_render_sample(state, C.byref(broken), 0, w * h, None))
+    finally:
+        lib.rt_wavefront_destroy(state)
+
+
 def test_reference_error_behaviour(R):
     scene = workloads.cornell_box()
     empty = dict(scene, instances=[])
