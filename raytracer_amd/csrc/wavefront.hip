@@ -287,7 +287,205 @@ __device__ inline bool lightTriangleDistance(const ShadeInstance* instances, con
                              distance, u, v);
 }
 
-// One bounce of device.cu:908-1041 for every path of queue `which`.
+// What one bounce leaves behind besides the path state it updates in place.
+struct ShadeOut {
+    bool continues = false, wantsShadow = false;
+    V3 origin{0, 0, 0}, direction{0, 0, 0};  // the next ray
+    V3 shadowOrigin{0, 0, 0}, shadowDirection{0, 0, 0}, contribution{0, 0, 0};
+    float shadowLimit = 0.0f;
+    uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
+    uint32_t gatherQueries = 0, gathered = 0;  // INLINE_GATHER only
+};
+
+// One bounce of device.cu:908-1041 for the path whose ray (origin, direction) met the scene at `h`.
+// INLINE_GATHER: the caustic gather is done here instead of being queued.
+template <bool INLINE_GATHER>
+__device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* instances,
+                                const rt_hit_group_data* geometries, const Buffers& b, uint32_t path, V3 origin,
+                                V3 direction, uint4 h, uint32_t hitInstance, uint32_t depth, ShadeOut& out) {
+    bool& continues = out.continues;
+    bool& wantsShadow = out.wantsShadow;
+    V3& shadowOrigin = out.shadowOrigin;
+    V3& shadowDirection = out.shadowDirection;
+    V3& contribution = out.contribution;
+    float& shadowLimit = out.shadowLimit;
+    uint32_t& shadowBits = out.shadowBits;
+    uint32_t& targetInstance = out.targetInstance;
+    uint32_t& targetPrimitive = out.targetPrimitive;
+    const float4 tp = b.throughput[path];
+    V3 throughput{tp.x, tp.y, tp.z};
+    float lastPdf = tp.w;
+    const float4 lo = b.lastOrigin[path];
+    const V3 lastOrigin{lo.x, lo.y, lo.z};
+    uint32_t flags = __float_as_uint(lo.w);
+    uint32_t lobe = flags & 3U;
+    bool lastDelta = flags & kLastDelta, primaryChain = flags & kPrimaryChain, guidePending = flags & kGuidePending;
+    int medium = static_cast<int>(flags >> 8) - 1;
+    uint32_t rng = b.rng[path];
+
+    if (h.w == kNoHit) {
+        // device.cu:910-915
+        const float pdf = lastDelta ? 0.0f : environmentDensity(p, direction);
+        const float weight = lastDelta ? 1.0f : powerHeuristic(lastPdf, pdf);
+        const float4 r = b.sample[lobe][path];
+        const V3 sum = rgb(r) + throughput * environmentRadiance(p, direction) * weight;
+        b.sample[lobe][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    } else {
+        rt_hit hit;
+        reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
+                       __uint_as_float(h.z), h.w, hitInstance, hit);
+        const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
+        const V3 normal = shadingNormal(p.textures, hit, m);
+        hit.normal = r3(normal);
+        const V3 view = -direction;
+        if (depth == 0U) {
+            // device.cu:920-931
+            lobe = m.transmission > 0.5f ? 2U : m.metallic > 0.5f ? 1U : 0U;
+            b.sample[5][path] = make_float4(dot(normal, v3(p.lensU)), dot(normal, v3(p.lensV)),
+                                            dot(normal, v3(p.cameraW)), 0.0f);
+        }
+        if (guidePending) {
+            // device.cu:932-940
+            const bool clearGlass = m.transmission > 0.95f && m.roughness < 0.1f;
+            if (!clearGlass) {
+                if (m.transmission < 0.05f)
+                    b.sample[4][path] = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, 0.0f);
+                guidePending = false;
+            }
+        }
+        if (medium >= 0)
+            throughput = throughput * mediumAbsorption(p.materials[medium], hit.distance);
+        // device.cu:943-947
+        const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, lastOrigin, hit);
+        const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
+        V3 radiance = rgb(b.sample[lobe][path]);
+        radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
+
+        // next event estimation, device.cu:580-605; the visibility query is
+        // deferred to the shadow stage, which adds `contribution` when the
+        // light is seen
+        const float diffuseWeight = (1.0f - m.metallic) * (1.0f - m.transmission);
+        if (diffuseWeight > 0.0f) {
+            const LightDraw light = drawLight(p, v3(hit.position), rng);
+            const float cosine = dot(normal, light.direction);
+            if (light.valid && cosine > 0.0f) {
+                const V3 reflectance = schlickFresnel(normalReflectance(m), fmaxf(dot(view, normal), 0.0f));
+                const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
+                const V3 bsdf = rgb(m.baseColor) * diffuse * (diffuseWeight / 3.14159265f);
+                const float bsdfPdf = (1.0f - m.transmission) * (1.0f - specularChoice(m, view, normal)) * cosine /
+                                      3.14159265f;
+                const float weight = light.delta ? 1.0f : powerHeuristic(light.pdf, bsdfPdf);
+                contribution = throughput * (bsdf * light.radiance * (cosine * weight / light.pdf));
+                wantsShadow = true;
+                shadowOrigin = v3(hit.position) + normal * 0.001f;  // device.cu:550-552
+                shadowDirection = light.direction;
+                shadowLimit = light.delta ? light.distance - 0.002f : light.distance + 0.002f;
+                shadowBits = lobe;
+                if (!light.environment && !light.delta) {
+                    // the light's own triangle bounds the search (see traceKernel); a ray
+                    // that does not reach it at all cannot see the light
+                    targetInstance = light.instance;
+                    targetPrimitive = light.primitive;
+                    float distance = 0.0f;
+                    wantsShadow = lightTriangleDistance(instances, geometries, targetInstance, targetPrimitive,
+                                                        shadowOrigin, shadowDirection, 0.001f, shadowLimit, distance);
+                    shadowLimit = distance;
+                }
+            }
+        }
+        b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+
+        // caustic gather, device.cu:722-766, 949-950
+    if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
+        const float radiusSquared = p.photonRadius * p.photonRadius;
+        const float kernel = 2.0f / (3.14159265f * radiusSquared * 3.14159265f);
+        const V3 weight = rgb(m.baseColor) * (diffuseWeight * kernel);
+        if (INLINE_GATHER) {
+            // the three float operations of causticGatherKernel, on the spot
+            float fx, fy, fz;
+            uint32_t gathered = 0;
+            gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, hit.position.x,
+                       hit.position.y, hit.position.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered,
+                       b.bucketBits);
+            const V3 caustic = weight * V3{fx, fy, fz};
+            const V3 sum = rgb(b.sample[3][path]) + throughput * caustic;
+            b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+            out.gatherQueries = 1;
+            out.gathered = gathered;
+        } else {
+            // the query is left for causticGatherKernel, which walks the photon map with dense
+            // waves instead of the few lanes that want it here
+            const unsigned long long votes = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            uint32_t base = 0;
+            if (lane == __ffsll(static_cast<long long>(votes)) - 1)
+                base = atomicAdd(&b.counts[3], static_cast<uint32_t>(__popcll(votes)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t query = base + __popcll(votes & ((1ULL << lane) - 1ULL));
+            b.gather[0][query] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(path));
+            b.gather[1][query] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+            b.gather[2][query] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+            b.gather[3][query] = make_float4(weight.x, weight.y, weight.z, 0.0f);
+        }
+    }
+
+    // scattering, device.cu:952-1032
+        continues = true;
+        const bool transmissive = m.transmission > 0.0f && random01(rng) < m.transmission;
+        if (transmissive) {
+            lastDelta = true;
+            continues = dielectricEvent(m, hit, rng, origin, direction, throughput, medium);
+        } else {
+            const V3 color = rgb(m.baseColor);
+            const V3 f0 = normalReflectance(m);
+            const float viewCosine = fmaxf(dot(view, normal), 0.0f);
+            const float probability = specularChoice(m, view, normal);
+            if (random01(rng) < probability) {
+                lastDelta = true;
+                const float alpha = alphaOf(m.roughness);
+                const V3 microNormal = sampleVisibleNormal(view, normal, alpha, rng);
+                direction = reflectAbout(direction, microNormal);
+                const float lightCosine = dot(direction, normal);
+                if (lightCosine <= 0.0f)
+                    continues = false;
+                else
+                    throughput = throughput * (schlickFresnel(f0, fmaxf(dot(view, microNormal), 0.0f)) *
+                                               (maskingRatio(viewCosine, lightCosine, alpha) / probability));
+            } else {
+                lastDelta = false;
+                primaryChain = false;
+                direction = sampleCosine(normal, rng);
+                const V3 reflectance = schlickFresnel(f0, viewCosine);
+                const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
+                throughput = throughput * (color * diffuse * ((1.0f - m.metallic) / (1.0f - probability)));
+                lastPdf = (1.0f - m.transmission) * (1.0f - probability) * fmaxf(dot(normal, direction), 0.0f) /
+                          3.14159265f;
+            }
+            origin = v3(hit.position) + normal * 0.001f;
+        }
+        // Russian roulette, device.cu:1035-1040
+        if (continues && depth > 2U) {
+            const float survival = fminf(fmaxf(maximum(throughput), 0.05f), 0.95f);
+            if (random01(rng) > survival)
+                continues = false;
+            else
+                throughput = throughput / survival;
+        }
+        if (depth + 1U >= p.maxDepth)
+            continues = false;
+        if (continues) {
+            b.rng[path] = rng;
+            b.throughput[path] = make_float4(throughput.x, throughput.y, throughput.z, lastPdf);
+            flags = lobe | (lastDelta ? kLastDelta : 0U) | (primaryChain ? kPrimaryChain : 0U) |
+                    (guidePending ? kGuidePending : 0U) | static_cast<uint32_t>(medium + 1) << 8;
+            b.lastOrigin[path] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(flags));
+        }
+    }
+    out.origin = origin;
+    out.direction = direction;
+}
+
+// One bounce for every path of queue `which`.
 __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                            const rt_hit_group_data* geometries, Buffers b, int which,
                                                            uint32_t depth) {
@@ -296,177 +494,20 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     if (blockIdx.x * kShadeBlock >= n)
         return;  // whole workgroup idle
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
-    const bool active = slot < n;
-
-    bool continues = false, wantsShadow = false;
-    V3 origin{0, 0, 0}, direction{0, 0, 0};
-    V3 shadowOrigin{0, 0, 0}, shadowDirection{0, 0, 0}, contribution{0, 0, 0};
-    float shadowLimit = 0.0f;
-    uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
+    ShadeOut out;
     uint32_t path = 0;
-
-    if (active) {
+    if (slot < n) {
         path = b.rayPath[which][slot];
         const float4 o4 = b.rayOrigin[which][slot];
         const float4 d4 = b.rayDirection[which][slot];
-        origin = V3{o4.x, o4.y, o4.z};
-        direction = V3{d4.x, d4.y, d4.z};
-        const uint4 h = b.hits[slot];
-        const float4 tp = b.throughput[path];
-        V3 throughput{tp.x, tp.y, tp.z};
-        float lastPdf = tp.w;
-        const float4 lo = b.lastOrigin[path];
-        const V3 lastOrigin{lo.x, lo.y, lo.z};
-        uint32_t flags = __float_as_uint(lo.w);
-        uint32_t lobe = flags & 3U;
-        bool lastDelta = flags & kLastDelta, primaryChain = flags & kPrimaryChain, guidePending = flags & kGuidePending;
-        int medium = static_cast<int>(flags >> 8) - 1;
-        uint32_t rng = b.rng[path];
-
-        if (h.w == kNoHit) {
-            // device.cu:910-915
-            const float pdf = lastDelta ? 0.0f : environmentDensity(p, direction);
-            const float weight = lastDelta ? 1.0f : powerHeuristic(lastPdf, pdf);
-            const float4 r = b.sample[lobe][path];
-            const V3 sum = rgb(r) + throughput * environmentRadiance(p, direction) * weight;
-            b.sample[lobe][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-        } else {
-            rt_hit hit;
-            reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
-                           __uint_as_float(h.z), h.w, b.hitInstance[slot], hit);
-            const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
-            const V3 normal = shadingNormal(p.textures, hit, m);
-            hit.normal = r3(normal);
-            const V3 view = -direction;
-            if (depth == 0U) {
-                // device.cu:920-931
-                lobe = m.transmission > 0.5f ? 2U : m.metallic > 0.5f ? 1U : 0U;
-                b.sample[5][path] = make_float4(dot(normal, v3(p.lensU)), dot(normal, v3(p.lensV)),
-                                                dot(normal, v3(p.cameraW)), 0.0f);
-            }
-            if (guidePending) {
-                // device.cu:932-940
-                const bool clearGlass = m.transmission > 0.95f && m.roughness < 0.1f;
-                if (!clearGlass) {
-                    if (m.transmission < 0.05f)
-                        b.sample[4][path] = make_float4(m.baseColor.x, m.baseColor.y, m.baseColor.z, 0.0f);
-                    guidePending = false;
-                }
-            }
-            if (medium >= 0)
-                throughput = throughput * mediumAbsorption(p.materials[medium], hit.distance);
-            // device.cu:943-947
-            const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, lastOrigin, hit);
-            const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
-            V3 radiance = rgb(b.sample[lobe][path]);
-            radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
-
-            // next event estimation, device.cu:580-605; the visibility query is
-            // deferred to the shadow stage, which adds `contribution` when the
-            // light is seen
-            const float diffuseWeight = (1.0f - m.metallic) * (1.0f - m.transmission);
-            if (diffuseWeight > 0.0f) {
-                const LightDraw light = drawLight(p, v3(hit.position), rng);
-                const float cosine = dot(normal, light.direction);
-                if (light.valid && cosine > 0.0f) {
-                    const V3 reflectance = schlickFresnel(normalReflectance(m), fmaxf(dot(view, normal), 0.0f));
-                    const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
-                    const V3 bsdf = rgb(m.baseColor) * diffuse * (diffuseWeight / 3.14159265f);
-                    const float bsdfPdf = (1.0f - m.transmission) * (1.0f - specularChoice(m, view, normal)) * cosine /
-                                          3.14159265f;
-                    const float weight = light.delta ? 1.0f : powerHeuristic(light.pdf, bsdfPdf);
-                    contribution = throughput * (bsdf * light.radiance * (cosine * weight / light.pdf));
-                    wantsShadow = true;
-                    shadowOrigin = v3(hit.position) + normal * 0.001f;  // device.cu:550-552
-                    shadowDirection = light.direction;
-                    shadowLimit = light.delta ? light.distance - 0.002f : light.distance + 0.002f;
-                    shadowBits = lobe;
-                    if (!light.environment && !light.delta) {
-                        // the light's own triangle bounds the search (see traceKernel); a ray
-                        // that does not reach it at all cannot see the light
-                        targetInstance = light.instance;
-                        targetPrimitive = light.primitive;
-                        float distance = 0.0f;
-                        wantsShadow = lightTriangleDistance(instances, geometries, targetInstance, targetPrimitive,
-                                                            shadowOrigin, shadowDirection, 0.001f, shadowLimit, distance);
-                        shadowLimit = distance;
-                    }
-                }
-            }
-            b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-
-            // caustic gather, device.cu:722-766, 949-950: the query is left for causticGatherKernel,
-            // which walks the photon map with dense waves instead of the few lanes that want it here
-            if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
-                const unsigned long long votes = __ballot(1);
-                const int lane = threadIdx.x & 63;
-                uint32_t base = 0;
-                if (lane == __ffsll(static_cast<long long>(votes)) - 1)
-                    base = atomicAdd(&b.counts[3], static_cast<uint32_t>(__popcll(votes)));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint32_t query = base + __popcll(votes & ((1ULL << lane) - 1ULL));
-                const float radiusSquared = p.photonRadius * p.photonRadius;
-                const float kernel = 2.0f / (3.14159265f * radiusSquared * 3.14159265f);
-                const V3 weight = rgb(m.baseColor) * (diffuseWeight * kernel);
-                b.gather[0][query] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(path));
-                b.gather[1][query] = make_float4(normal.x, normal.y, normal.z, 0.0f);
-                b.gather[2][query] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
-                b.gather[3][query] = make_float4(weight.x, weight.y, weight.z, 0.0f);
-            }
-
-            // scattering, device.cu:952-1032
-            continues = true;
-            const bool transmissive = m.transmission > 0.0f && random01(rng) < m.transmission;
-            if (transmissive) {
-                lastDelta = true;
-                continues = dielectricEvent(m, hit, rng, origin, direction, throughput, medium);
-            } else {
-                const V3 color = rgb(m.baseColor);
-                const V3 f0 = normalReflectance(m);
-                const float viewCosine = fmaxf(dot(view, normal), 0.0f);
-                const float probability = specularChoice(m, view, normal);
-                if (random01(rng) < probability) {
-                    lastDelta = true;
-                    const float alpha = alphaOf(m.roughness);
-                    const V3 microNormal = sampleVisibleNormal(view, normal, alpha, rng);
-                    direction = reflectAbout(direction, microNormal);
-                    const float lightCosine = dot(direction, normal);
-                    if (lightCosine <= 0.0f)
-                        continues = false;
-                    else
-                        throughput = throughput * (schlickFresnel(f0, fmaxf(dot(view, microNormal), 0.0f)) *
-                                                   (maskingRatio(viewCosine, lightCosine, alpha) / probability));
-                } else {
-                    lastDelta = false;
-                    primaryChain = false;
-                    direction = sampleCosine(normal, rng);
-                    const V3 reflectance = schlickFresnel(f0, viewCosine);
-                    const V3 diffuse{1.0f - reflectance.x, 1.0f - reflectance.y, 1.0f - reflectance.z};
-                    throughput = throughput * (color * diffuse * ((1.0f - m.metallic) / (1.0f - probability)));
-                    lastPdf = (1.0f - m.transmission) * (1.0f - probability) * fmaxf(dot(normal, direction), 0.0f) /
-                              3.14159265f;
-                }
-                origin = v3(hit.position) + normal * 0.001f;
-            }
-            // Russian roulette, device.cu:1035-1040
-            if (continues && depth > 2U) {
-                const float survival = fminf(fmaxf(maximum(throughput), 0.05f), 0.95f);
-                if (random01(rng) > survival)
-                    continues = false;
-                else
-                    throughput = throughput / survival;
-            }
-            if (depth + 1U >= p.maxDepth)
-                continues = false;
-            if (continues) {
-                b.rng[path] = rng;
-                b.throughput[path] = make_float4(throughput.x, throughput.y, throughput.z, lastPdf);
-                flags = lobe | (lastDelta ? kLastDelta : 0U) | (primaryChain ? kPrimaryChain : 0U) |
-                        (guidePending ? kGuidePending : 0U) | static_cast<uint32_t>(medium + 1) << 8;
-                b.lastOrigin[path] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(flags));
-            }
-        }
+        shadeOne<false>(p, instances, geometries, b, path, V3{o4.x, o4.y, o4.z}, V3{d4.x, d4.y, d4.z}, b.hits[slot],
+                        b.hitInstance[slot], depth, out);
     }
+    const bool continues = out.continues, wantsShadow = out.wantsShadow;
+    const V3 origin = out.origin, direction = out.direction;
+    const V3 shadowOrigin = out.shadowOrigin, shadowDirection = out.shadowDirection, contribution = out.contribution;
+    const float shadowLimit = out.shadowLimit;
+    const uint32_t shadowBits = out.shadowBits, targetInstance = out.targetInstance, targetPrimitive = out.targetPrimitive;
 
     const int next = which ^ 1;
     uint32_t nextSlot, shadowSlot;
