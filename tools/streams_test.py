@@ -1,5 +1,8 @@
+"""Development aid: step time of the tiled renderer in a process that owns other HIP streams, created
+before or after the renderer (python tools/streams_test.py <extra streams> before|after): shows whether
+the renderer's streams ended up on hardware queues of their own."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from raytracer_amd import renderer as R, workloads
 extra = int(sys.argv[1]); when = sys.argv[2]
