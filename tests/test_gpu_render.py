@@ -292,6 +292,23 @@ def test_concurrent_tiles_do_not_change_the_image(R):
         assert np.array_equal(pixels, images[0][0])
         assert np.array_equal(bytes8, images[0][1])
         assert stats["extend_rays"] == images[0][2]["extend_rays"] and stats["refused_references"] == 0
+    # the final profile: every part has photon query queues of its own and shares the photon map
+    scene = workloads.caustic_lab()
+    w, h = 64, 40
+    images = []
+    for tiles in (1, 3, 4):
+        r = R.Renderer(scene, w, h, 1)
+        r.set_photon_budget(1 << 19, 1 << 18, 1 << 14)
+        r.set_concurrent_tiles(tiles)
+        for _ in range(5):           # photon passes before samples 0 and 4
+            r.render()
+        r.synchronize()
+        images.append((np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]),
+                       r.statistics()))
+    for buffers, stats in images[1:]:
+        assert np.array_equal(buffers, images[0][0])
+        assert stats == images[0][1]
+    assert images[0][1]["gather_queries"] > 0
 
 
 def test_ray_share_does_not_change_the_image(R):
