@@ -214,6 +214,27 @@ def test_sample_launch_through_the_c_abi(R, engine):
         lib.rt_wavefront_destroy(state)
 
 
+def test_tiny_photon_budgets(R, oracle):
+    """Photon budgets at the lower end: one bucket (every neighbour cell is the same bucket), two buckets,
+    a capacity of one photon (the buffer overflows and the map keeps what fits), one emission.  The
+    buffers stay finite, no reference is refused, and the dense one- and two-bucket maps still light the
+    caustic buffer."""
+    scene = workloads.caustic_lab()
+    w, h = 40, 24
+    for emissions, capacity, buckets in ((1 << 16, 1 << 15, 1), (1 << 16, 1 << 15, 2), (1 << 14, 1, 64), (1, 1, 1)):
+        r = R.Renderer(scene, w, h, 1)
+        r.set_photon_budget(emissions, capacity, buckets)
+        for _ in range(2):
+            r.render()
+        r.synchronize()
+        buffers = np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16).view(np.float32) for k in range(7)])
+        assert np.isfinite(buffers).all(), (emissions, capacity, buckets)
+        stats = r.statistics()
+        assert stats["refused_references"] == 0 and stats["gather_queries"] > 0
+        if buckets <= 2 and emissions > 1:
+            assert stats["gathered_photons"] > 0 and buffers[4].reshape(-1, 4)[:, :3].sum() > 0
+
+
 def test_reference_error_behaviour(R):
     scene = workloads.cornell_box()
     empty = dict(scene, instances=[])
