@@ -36,6 +36,10 @@ __device__ inline uint32_t bucketOfPosition(float px, float py, float pz, float 
 #define RT_GATHER_CHUNK 8
 #endif
 constexpr uint32_t kGatherChunk = RT_GATHER_CHUNK;
+// waves per SIMD the per-lane gather kernels are compiled for
+#ifndef RT_GATHER_WAVES
+#define RT_GATHER_WAVES 8
+#endif
 
 // Flux sum of one query in the reference's own order (cells z, y, x from -1 to
 // 1, a bucket reached twice counted once, photons in stored order), so the

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bucketBitmapKernel(const uint32_t* cellSt
 }
 
 // One query per lane.
-__global__ __launch_bounds__(256, 8) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
+__global__ __launch_bounds__(256, RT_GATHER_WAVES) void photonGatherKernel(const rt_photon* sorted, const uint32_t* cellStart,
                                                           uint32_t bucketCount, float radius, const float* qpos,
                                                           const float* qnormal, uint32_t n, float* flux,
                                                           unsigned long long* visitedTotal,

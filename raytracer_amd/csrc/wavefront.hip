@@ -540,7 +540,7 @@ constexpr unsigned kHeavyGatherBlocks = 512;
 // estimate to the caustic sum of its path.  A path has at most one query per bounce, so the
 // order of the queue does not enter any sum.  Queries over the photon budget go on to
 // causticGatherHeavyKernel.
-__global__ __launch_bounds__(kShadeBlock, 8) void causticGatherKernel(rt_launch_params p, Buffers b) {
+__global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKernel(rt_launch_params p, Buffers b) {
     const uint32_t n = b.counts[3];
     if (blockIdx.x * kShadeBlock >= n)
         return;
