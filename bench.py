@@ -36,8 +36,8 @@ NODE_BYTES, TRIANGLE_BYTES, RAY_IO_BYTES = 80.0, 36.0, 52.0  # algorithmic bytes
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--workload", default="dragon-cornell",
