@@ -123,7 +123,11 @@ typedef struct rt_instance_desc {
 } rt_instance_desc;
 
 /* optixAccelBuild over instances (src/renderer.cpp:414-432).  `instances` is
- * host memory.  The BLASes must outlive the scene. */
+ * host memory.  The BLASes must outlive the scene.  Returns
+ * RT_ERROR_OUT_OF_RANGE when the tree over the instances plus the deepest
+ * bottom-level tree has more levels (18) than the traversal stack of the ray
+ * kernels can follow: such a scene is refused here rather than traced with
+ * dropped stack entries. */
 rt_status rt_scene_build(const rt_instance_desc* instances, uint32_t instanceCount, void* stream, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 /* The hit-group records of the shader binding table (src/renderer.cpp:649-660):

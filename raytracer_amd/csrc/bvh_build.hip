@@ -1134,6 +1134,11 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     scene->nodeCount = builder.nodes.size();
     scene->instanceCount = count;
     scene->depth = builder.depth;
+    if (!fitsTraversalStack(scene->depth, scene->blasDepth)) {
+        setLastError("tree too deep for the traversal stack: " + std::to_string(scene->depth) + " top levels + " +
+                     std::to_string(scene->blasDepth) + " bottom levels");
+        return RT_ERROR_OUT_OF_RANGE;
+    }
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->nodes), sizeof(WideNode) * builder.nodes.size()));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * count));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->feedCursors), sizeof(uint32_t) * kFeedWords * kFeedSlots));

@@ -43,7 +43,7 @@ constexpr unsigned divUp(unsigned long long a, unsigned long long b) {
     return static_cast<unsigned>((a + b - 1) / b);
 }
 
-inline size_t alignUp(size_t value, size_t alignment) {
+constexpr size_t alignUp(size_t value, size_t alignment) {
     return (value + alignment - 1) / alignment * alignment;
 }
 

@@ -22,9 +22,9 @@ constexpr int kScanItems = 16;
 constexpr int kScanTile = kScanBlock * kScanItems;    // 4096 values per workgroup
 constexpr int kScanMaxPartials = 1024 * 64;           // one workgroup scans the partial sums
 
-inline unsigned sortBlocks(uint32_t n) { return n ? divUp(n, kSortTile) : 0U; }
-inline size_t sortTableEntries(uint32_t n) { return static_cast<size_t>(kRadix) * sortBlocks(n); }
-inline size_t scanScratchEntries(size_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+constexpr unsigned sortBlocks(uint32_t n) { return n ? divUp(n, kSortTile) : 0U; }
+constexpr size_t sortTableEntries(uint32_t n) { return static_cast<size_t>(kRadix) * sortBlocks(n); }
+constexpr size_t scanScratchEntries(size_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
 
 // Exclusive scan of `value` across the workgroup; `total` is the workgroup sum.
 template <int BLOCK>

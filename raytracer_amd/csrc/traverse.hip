@@ -96,9 +96,7 @@ rt_status checkScene(const rt_scene* scene) {
     RT_HIP(hipGetDevice(&device));
     if (device != scene->device)
         return failInvalid("scene was built on another device");
-    // every visited node leaves at most seven entries behind, plus one marker
-    // per instance entered
-    if ((kWide - 1) * (scene->depth + scene->blasDepth) + 2 > static_cast<uint32_t>(kMaxStack)) {
+    if (!fitsTraversalStack(scene->depth, scene->blasDepth)) {  // rt_scene_build refuses such a scene already
         setLastError("tree too deep for the traversal stack");
         return RT_ERROR_OUT_OF_RANGE;
     }

@@ -56,6 +56,7 @@ constexpr int kTraceBlock = 256;
 constexpr int kLdsStack = RT_TRACE_LDS_STACK;  // entries per lane kept in LDS
 constexpr int kPrivateStack = 128 - kLdsStack;  // overflow entries per lane in private memory
 constexpr int kMaxStack = kLdsStack + kPrivateStack;
+static_assert(kMaxStack == static_cast<int>(kTraversalStackEntries), "fitsTraversalStack() assumes this stack size");
 constexpr uint32_t kLeafBit = 0x80000000U;
 constexpr uint32_t kSentinel = 0x7fffffffU;  // marks the return from an instance
 

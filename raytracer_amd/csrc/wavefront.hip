@@ -1048,6 +1048,10 @@ static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* para
         return failInvalid("rt_scene_set_geometry has not been called");
     if (!params->materials)
         return failInvalid("launch parameters carry no materials");
+    if (!fitsTraversalStack(scene->depth, scene->blasDepth)) {  // rt_scene_build refuses such a scene already
+        setLastError("tree too deep for the traversal stack");
+        return RT_ERROR_OUT_OF_RANGE;
+    }
     return RT_SUCCESS;
 }
 

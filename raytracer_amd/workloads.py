@@ -302,9 +302,10 @@ def icosphere(subdivisions=4):
     return make_vertices(p, p.copy()), f.astype(np.uint32)
 
 
-def sphere_field(count=500, seed=3, subdivisions=4):
+def sphere_field(count=500, seed=3, subdivisions=4, sky=False):
     """One icosphere geometry instanced `count` times on a disc plus three large
-    spheres and a ground quad: a two-level (instanced) scene."""
+    spheres and a ground quad: a two-level (instanced) scene seen through a thin
+    lens.  sky=True adds a latitude/longitude sky with a sun as environment light."""
     rng = np.random.default_rng(seed)
     sphere = icosphere(subdivisions)
     ground = quad([-30, 0, -30], [-30, 0, 30], [30, 0, 30], [30, 0, -30])
@@ -330,8 +331,9 @@ def sphere_field(count=500, seed=3, subdivisions=4):
                   nearPlane=0.01, aperture=0.1, focusDistance=10.0)
     lights = [dict(transform=look_at([5.0, 12.0, 5.0], [0.0, 0.0, 0.0]), color=(1.0, 1.0, 1.0), intensity=3.0,
                    range=float("inf"), innerCone=0.0, outerCone=0.7853982, type=0)]
+    environment = dict(pixels=sky_environment(128, 64), rotation=0.7, strength=1.0, exposure=0.0) if sky else None
     return dict(geometries=geos, instances=inst, materials=materials, lights=lights, cameras=[camera],
-                environment=None)
+                environment=environment)
 
 
 def triangle_soup(n, seed=4):

@@ -264,3 +264,32 @@ def test_index_beyond_the_vertices_is_rejected(engine):
         with pytest.raises(engine.EngineError, match="index"):
             engine.Blas(v, dev(broken))
     torch.cuda.synchronize()
+
+
+def test_tree_deeper_than_the_traversal_stack_is_refused(engine):
+    """Instances whose sizes and distances grow geometrically make the top-level sweep peel a few instances
+    off per cut: a chain of some forty wide nodes, deeper than the traversal stack can follow without
+    dropping entries.  The scene build refuses it with a message instead of letting rays miss hits, and
+    the renderer reports the same error; a chain short enough to fit still builds and traces."""
+    from raytracer_amd import renderer as R
+    R.load()
+    box = workloads.box_mesh([-0.5, -0.5, -0.5], [0.5, 0.5, 0.5])
+
+    def chain(count):
+        scene = workloads.cornell_box()
+        scene["geometries"] = [{"vertices": box[0], "indices": box[1], "material": 1}]
+        scene["instances"] = [(0, workloads.translation(3.0 * 1.3 ** k, 0.0, 0.0, 1.3 ** k))
+                              for k in range(-(count // 2), count - count // 2)]
+        return scene
+
+    deep = chain(300)
+    blas = engine.Blas(dev(deep["geometries"][0]["vertices"]), dev(deep["geometries"][0]["indices"].astype(np.int32)))
+    with pytest.raises(engine.EngineError, match="too deep"):
+        engine.Scene([(blas, m) for _, m in deep["instances"]])
+    with pytest.raises(engine.EngineError, match="too deep"):
+        R.Renderer(deep, 16, 16)
+    shallow = chain(40)
+    top = engine.Scene([(blas, m) for _, m in shallow["instances"]])
+    assert top.stats().maxDepth <= 18
+    o, d = workloads.random_rays(shallow, 1000, seed=1)
+    top.trace_closest(dev(o), dev(d))
