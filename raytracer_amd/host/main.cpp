@@ -1,229 +1,269 @@
-// Command-line renderer: raytracer <scene.gltf|scene.glb> [--profile preview|final] [--width pixels]
-// [--height pixels] [--samples count] [--denoise on|off] [--output image.png|image.exr]
+// Command-line front end of the engine.
 //
-// Same options, defaults and messages as the reference's src/main.cpp:100-230 (an output file implies
-// the final profile; final means 256 samples, preview 32).  Two differences: without --output the
-// reference opens its interactive viewer, which this build does not have, so --output is required; and
-// --denoise on is refused, the OptiX denoiser having no counterpart here.  After rendering, the ray
-// statistics of the engine are printed.
+//   raytracer <scene.gltf|scene.glb> [--profile preview|final] [--width pixels] [--height pixels]
+//             [--samples count] [--denoise on|off] [--output image.png|image.exr]
+//
+// Accepts the command lines of the reference's executable (flags, defaults and error texts of
+// src/main.cpp:100-170; the offline loop of :211-230): an output file without --profile means the
+// final profile, final renders 256 samples and preview 32 unless --samples says otherwise.
+// What differs, because two parts of the reference are outside this engine:
+//   * there is no viewer, so a command line without --output is an error instead of a window;
+//   * there is no denoiser.  The reference denoises a final render unless told --denoise off; here
+//     the same command line renders, prints a notice in place of the denoising step and writes the
+//     raw accumulation.  Asking for the denoiser by name (--denoise on) is an error.
+// After the image is written the engine's ray statistics are printed (Mrays/s, photon gathers/s),
+// which the reference does not have.
 #include "image.hpp"
 #include "renderer.hpp"
 #include "scene.hpp"
 
-#include <algorithm>
-#include <charconv>
 #include <chrono>
-#include <exception>
-#include <filesystem>
-#include <iomanip>
-#include <iostream>
-#include <optional>
-#include <sstream>
-#include <string_view>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
 #include <unistd.h>
 
 namespace {
 
-using Clock = std::chrono::steady_clock;
+// ---- time -------------------------------------------------------------------------------------
 
-double secondsSince(Clock::time_point start) { return std::chrono::duration<double>(Clock::now() - start).count(); }
-
-std::string duration(double seconds) {  // main.cpp:26-38
-    const auto value = static_cast<std::uint64_t>(seconds);
-    std::ostringstream out;
-    if (value >= 3600)
-        out << value / 3600 << 'h' << std::setw(2) << std::setfill('0') << value / 60 % 60 << 'm';
-    else if (value >= 60)
-        out << value / 60 << 'm' << std::setw(2) << std::setfill('0') << value % 60 << 's';
-    else
-        out << value << 's';
-    return out.str();
-}
-
-// One line per update: percent, samples, elapsed, rate, estimate (main.cpp:40-91); a bar on a terminal.
-class Progress {
+class Stopwatch {
 public:
-    explicit Progress(std::uint32_t total) : total_(total), terminal_(isatty(STDOUT_FILENO) != 0), start_(Clock::now()), last_(start_) {
-        show(0);
-    }
-    void show(std::uint32_t current) {
-        const auto now = Clock::now();
-        const auto interval = terminal_ ? std::chrono::milliseconds(100) : std::chrono::milliseconds(5000);
-        if (current != total_ && current && now - last_ < interval)
-            return;
-        last_ = now;
-        const double elapsed = std::chrono::duration<double>(now - start_).count();
-        const double rate = current / std::max(elapsed, 1e-6);
-        std::ostringstream line;
-        line << "Rendering ";
-        if (terminal_) {
-            constexpr std::uint32_t width = 24;
-            const auto filled = width * current / total_;
-            line << '[' << std::string(filled, '#') << std::string(width - filled, '.') << "] ";
-        }
-        line << std::setw(3) << 100U * current / total_ << "% | " << current << '/' << total_ << " spp | " << duration(elapsed);
-        if (current)
-            line << " | " << std::fixed << std::setprecision(2) << rate << " spp/s";
-        if (current && current != total_)
-            line << " | ETA " << duration((total_ - current) / rate);
-        if (terminal_)
-            std::cout << "\r\033[2K" << line.str() << std::flush;
-        else
-            std::cout << line.str() << '\n' << std::flush;
-    }
-    void finish() {
-        if (terminal_)
-            std::cout << '\n';
+    Stopwatch() : begin_(std::chrono::steady_clock::now()) {}
+    double seconds() const {
+        return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - begin_).count();
     }
 
 private:
-    std::uint32_t total_;
-    bool terminal_;
-    Clock::time_point start_, last_;
+    std::chrono::steady_clock::time_point begin_;
 };
 
-template <typename Function>
-void phase(std::string_view label, Function&& function) {
-    std::cout << label << "..." << std::flush;
-    const auto start = Clock::now();
-    function();
-    std::cout << " done in " << duration(secondsSince(start)) << '\n';
+// 42s, 3m07s, 2h05m: the reference's spelling of a span (main.cpp:26-38), whole seconds.
+std::string spanText(double seconds) {
+    const unsigned long long whole = seconds > 0.0 ? static_cast<unsigned long long>(seconds) : 0ULL;
+    char text[48];
+    if (whole < 60ULL)
+        std::snprintf(text, sizeof text, "%llus", whole);
+    else if (whole < 3600ULL)
+        std::snprintf(text, sizeof text, "%llum%02llus", whole / 60ULL, whole % 60ULL);
+    else
+        std::snprintf(text, sizeof text, "%lluh%02llum", whole / 3600ULL, whole / 60ULL % 60ULL);
+    return text;
 }
 
-struct Options {  // main.cpp:100-110
-    std::filesystem::path scene;
-    std::optional<std::filesystem::path> output;
-    rt::Profile profile = rt::Profile::Final;
-    std::uint32_t width = 1280;
-    std::uint32_t height = 720;
-    std::uint32_t samples = 32;
-    bool profileSet = false;
-    bool samplesSet = false;
-    bool denoise = false;
-    bool denoiseSet = false;
+// Runs `work` between "<label>..." and " done in <span>".
+void timedStep(const std::string& label, const std::function<void()>& work) {
+    std::printf("%s...", label.c_str());
+    std::fflush(stdout);
+    const Stopwatch watch;
+    work();
+    std::printf(" done in %s\n", spanText(watch.seconds()).c_str());
+}
+
+// ---- command line -----------------------------------------------------------------------------
+
+struct Request {
+    std::string scenePath;
+    std::string outputPath;          // empty: none given
+    bool final = true;               // main.cpp:103
+    bool profileGiven = false;
+    std::uint32_t width = 1280, height = 720;
+    std::uint32_t samples = 0;       // 0: not given, the profile decides
+    enum class Denoise { Default, On, Off } denoise = Denoise::Default;
 };
 
-std::uint32_t positiveInteger(std::string_view value, std::string_view name) {
-    std::uint32_t result = 0;
-    const auto parsed = std::from_chars(value.data(), value.data() + value.size(), result);
-    if (parsed.ec != std::errc{} || parsed.ptr != value.data() + value.size() || result == 0)
-        throw std::runtime_error("Invalid " + std::string(name));
-    return result;
+[[noreturn]] void refuse(const std::string& message) { throw std::runtime_error(message); }
+
+std::uint32_t countFrom(const char* text, const char* what) {
+    // digits only, no sign, no blanks, at least 1, fits 32 bits
+    std::uint64_t value = 0;
+    const char* p = text;
+    for (; *p >= '0' && *p <= '9' && value <= 0xffffffffULL; ++p)
+        value = value * 10U + static_cast<unsigned>(*p - '0');
+    if (p == text || *p != '\0' || value == 0 || value > 0xffffffffULL)
+        refuse(std::string("Invalid ") + what);
+    return static_cast<std::uint32_t>(value);
 }
 
-Options options(int argc, char** argv) {  // main.cpp:122-170
+Request readCommandLine(int argc, char** argv) {
     if (argc < 2)
-        throw std::runtime_error("usage: raytracer <scene.gltf|scene.glb> [--profile preview|final] "
-                                 "[--width pixels] [--height pixels] [--samples count] "
-                                 "[--denoise on|off] [--output image.png]");
-    Options result;
-    result.scene = argv[1];
-    for (int index = 2; index < argc; index += 2) {
-        if (index + 1 >= argc)
-            throw std::runtime_error("Missing option value");
-        const std::string_view name = argv[index], value = argv[index + 1];
-        if (name == "--output") {
-            result.output = std::filesystem::path(value);
-        } else if (name == "--profile") {
-            if (value == "preview")
-                result.profile = rt::Profile::Preview;
-            else if (value == "final")
-                result.profile = rt::Profile::Final;
-            else
-                throw std::runtime_error("Expected preview or final profile");
-            result.profileSet = true;
-        } else if (name == "--width") {
-            result.width = positiveInteger(value, "width");
-        } else if (name == "--height") {
-            result.height = positiveInteger(value, "height");
-        } else if (name == "--samples") {
-            result.samples = positiveInteger(value, "sample count");
-            result.samplesSet = true;
-        } else if (name == "--denoise") {
-            if (value == "on")
-                result.denoise = true;
-            else if (value == "off")
-                result.denoise = false;
-            else
-                throw std::runtime_error("Expected on or off for denoise");
-            result.denoiseSet = true;
-        } else {
-            throw std::runtime_error("Unknown option: " + std::string(name));
-        }
+        refuse("usage: raytracer <scene.gltf|scene.glb> [--profile preview|final] [--width pixels] [--height pixels] "
+               "[--samples count] [--denoise on|off] [--output image.png]");
+    Request request;
+    request.scenePath = argv[1];
+    struct Flag {
+        const char* name;
+        std::function<void(const char*)> take;
+    };
+    const Flag flags[] = {
+        {"--output", [&](const char* v) { request.outputPath = v; }},
+        {"--profile",
+         [&](const char* v) {
+             if (std::strcmp(v, "preview") != 0 && std::strcmp(v, "final") != 0)
+                 refuse("Expected preview or final profile");
+             request.final = v[0] == 'f';
+             request.profileGiven = true;
+         }},
+        {"--width", [&](const char* v) { request.width = countFrom(v, "width"); }},
+        {"--height", [&](const char* v) { request.height = countFrom(v, "height"); }},
+        {"--samples", [&](const char* v) { request.samples = countFrom(v, "sample count"); }},
+        {"--denoise",
+         [&](const char* v) {
+             if (std::strcmp(v, "on") == 0)
+                 request.denoise = Request::Denoise::On;
+             else if (std::strcmp(v, "off") == 0)
+                 request.denoise = Request::Denoise::Off;
+             else
+                 refuse("Expected on or off for denoise");
+         }},
+    };
+    for (int at = 2; at < argc; at += 2) {
+        if (at + 1 == argc)
+            refuse("Missing option value");
+        const Flag* match = nullptr;
+        for (const Flag& flag : flags)
+            if (std::strcmp(flag.name, argv[at]) == 0)
+                match = &flag;
+        if (!match)
+            refuse(std::string("Unknown option: ") + argv[at]);
+        match->take(argv[at + 1]);
     }
-    if (result.output && !result.profileSet)
-        result.profile = rt::Profile::Final;
-    if (!result.samplesSet)
-        result.samples = result.profile == rt::Profile::Final ? 256U : 32U;
-    return result;
+    if (!request.outputPath.empty() && !request.profileGiven)
+        request.final = true;                         // main.cpp:165-166
+    if (request.samples == 0)
+        request.samples = request.final ? 256U : 32U;  // main.cpp:167-168
+    return request;
+}
+
+bool endsWith(const std::string& text, const char* suffix) {
+    const std::size_t n = std::strlen(suffix);
+    return text.size() >= n && text.compare(text.size() - n, n, suffix) == 0;
+}
+
+// ---- progress ---------------------------------------------------------------------------------
+
+// "Rendering  37% | 12/32 spp | 4s | 2.81 spp/s | ETA 7s" (main.cpp:56-77): redrawn in place with a
+// bar every 100 ms on a terminal, a new line every 5 s otherwise; the first and the last state always.
+class SampleMeter {
+public:
+    explicit SampleMeter(std::uint32_t goal) : goal_(goal), onTerminal_(isatty(STDOUT_FILENO) == 1) { report(0); }
+
+    void report(std::uint32_t done) {
+        const double now = watch_.seconds();
+        const bool edge = done == 0 || done == goal_;
+        if (!edge && now - lastReport_ < (onTerminal_ ? 0.1 : 5.0))
+            return;
+        lastReport_ = now;
+        std::string line = "Rendering ";
+        if (onTerminal_) {
+            const std::uint32_t cells = 24, full = static_cast<std::uint32_t>(std::uint64_t(cells) * done / goal_);
+            line += '[' + std::string(full, '#') + std::string(cells - full, '.') + "] ";
+        }
+        char part[96];
+        std::snprintf(part, sizeof part, "%3u%% | %u/%u spp | %s", static_cast<unsigned>(100ULL * done / goal_), done, goal_,
+                      spanText(now).c_str());
+        line += part;
+        if (done) {
+            const double rate = done / (now > 1e-6 ? now : 1e-6);
+            std::snprintf(part, sizeof part, " | %.2f spp/s", rate);
+            line += part;
+            if (done != goal_)
+                line += " | ETA " + spanText((goal_ - done) / rate);
+        }
+        std::printf(onTerminal_ ? "\r\033[2K%s" : "%s\n", line.c_str());
+        std::fflush(stdout);
+    }
+
+    void close() const {
+        if (onTerminal_)
+            std::printf("\n");
+    }
+
+private:
+    std::uint32_t goal_;
+    bool onTerminal_;
+    Stopwatch watch_;
+    double lastReport_ = 0.0;
+};
+
+void describe(const Request& request, const rt::Scene& scene) {  // main.cpp:185-204
+    std::printf("Loaded \"%s\"\n", request.scenePath.c_str());
+    std::printf("  %zu geometries, %zu instances\n", scene.geometries.size(), scene.instances.size());
+    std::printf("  %zu materials, %zu textures, %zu images\n", scene.materials.size(), scene.textures.size(),
+                scene.images.size());
+    std::printf("  %zu cameras, %zu lights\n", scene.cameras.size(), scene.lights.size());
+    if (!scene.cameras.empty())
+        std::printf("  camera aperture %g, focus %g m\n", scene.cameras.front().aperture, scene.cameras.front().focusDistance);
+    if (!scene.environment.pixels.empty())
+        std::printf("  HDRI %ux%u, strength %g\n", scene.environment.width, scene.environment.height, scene.environment.strength);
+    std::printf("  profile %s, %ux%u\n", request.final ? "final" : "preview", request.width, request.height);
+}
+
+int run(int argc, char** argv) {
+    const Request request = readCommandLine(argc, argv);
+    if (request.outputPath.empty())
+        refuse("this build has no interactive viewer: pass --output image.png or image.exr");
+    const bool exr = endsWith(request.outputPath, ".exr");
+    if (!exr && !endsWith(request.outputPath, ".png"))
+        refuse("Output must use .png or .exr");
+    if (request.denoise == Request::Denoise::On)
+        refuse("the OptiX denoiser is not part of this build: use --denoise off");
+
+    rt::Scene scene;
+    timedStep("Loading \"" + request.scenePath + "\"", [&] { scene = rt::loadScene(request.scenePath); });
+    describe(request, scene);
+
+    const rt::Profile profile = request.final ? rt::Profile::Final : rt::Profile::Preview;
+    std::unique_ptr<rt::Renderer> renderer;
+    timedStep("Initializing renderer",
+              [&] { renderer = std::make_unique<rt::Renderer>(scene, request.width, request.height, profile); });
+
+    const Stopwatch renderWatch;
+    SampleMeter meter(request.samples);
+    while (renderer->samples() < request.samples) {
+        renderer->render();
+        // render() only queues work: wait now and then so that the rate shown is the rate achieved
+        if (renderer->samples() % 8U == 0U || renderer->samples() == request.samples)
+            renderer->synchronize();
+        meter.report(renderer->samples());
+    }
+    meter.close();
+    const double renderSeconds = renderWatch.seconds();
+
+    if (request.final && request.denoise == Request::Denoise::Default)
+        std::printf("Denoising with OptiX... skipped: this build has no denoiser, the raw accumulation is written\n");
+    timedStep("Writing " + request.outputPath, [&] {
+        if (exr)
+            rt::writeExr(request.outputPath, request.width, request.height, renderer->linearPixels());
+        else
+            rt::writePng(request.outputPath, request.width, request.height, renderer->pixels());
+    });
+    std::printf("Done at %u spp\n", renderer->samples());
+
+    std::uint64_t counters[8] = {};
+    renderer->statistics(counters);
+    const double span = renderSeconds > 1e-9 ? renderSeconds : 1e-9;
+    std::printf("  %.1f Mrays/s (%" PRIu64 " closest-hit + %" PRIu64 " shadow rays in %.2f s)",
+                static_cast<double>(counters[0] + counters[1]) / span / 1e6, counters[0], counters[1], renderSeconds);
+    if (counters[2])
+        std::printf(", %.1f M photon gathers/s", static_cast<double>(counters[2]) / span / 1e6);
+    std::printf("\n");
+    return 0;
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
     try {
-        const auto arguments = options(argc, argv);
-        if (!arguments.output)
-            throw std::runtime_error("this build has no interactive viewer: pass --output image.png or image.exr");
-        if (arguments.output->extension() != ".png" && arguments.output->extension() != ".exr")
-            throw std::runtime_error("Output must use .png or .exr");
-        if (arguments.denoise)
-            throw std::runtime_error("the OptiX denoiser is not part of this build: use --denoise off");
-        const auto width = arguments.width, height = arguments.height;
-        const auto loadStart = Clock::now();
-        std::cout << "Loading " << arguments.scene << "..." << std::flush;
-        const auto scene = rt::loadScene(arguments.scene);
-        std::cout << " done in " << duration(secondsSince(loadStart)) << '\n';
-        std::cout << "Loaded " << arguments.scene << '\n'  // main.cpp:183-199
-                  << "  " << scene.geometries.size() << " geometries, " << scene.instances.size() << " instances\n"
-                  << "  " << scene.materials.size() << " materials, " << scene.textures.size() << " textures, "
-                  << scene.images.size() << " images\n"
-                  << "  " << scene.cameras.size() << " cameras, " << scene.lights.size() << " lights\n";
-        if (!scene.cameras.empty())
-            std::cout << "  camera aperture " << scene.cameras.front().aperture << ", focus "
-                      << scene.cameras.front().focusDistance << " m\n";
-        if (!scene.environment.pixels.empty())
-            std::cout << "  HDRI " << scene.environment.width << 'x' << scene.environment.height << ", strength "
-                      << scene.environment.strength << '\n';
-        std::cout << "  profile " << (arguments.profile == rt::Profile::Final ? "final" : "preview") << ", " << width << 'x'
-                  << height << '\n';
-
-        const auto initializeStart = Clock::now();
-        std::cout << "Initializing renderer..." << std::flush;
-        rt::Renderer renderer(scene, width, height, arguments.profile);
-        std::cout << " done in " << duration(secondsSince(initializeStart)) << '\n';
-
-        const auto renderStart = Clock::now();
-        Progress progress(arguments.samples);
-        while (renderer.samples() < arguments.samples) {
-            renderer.render();
-            if (renderer.samples() % 8U == 0U || renderer.samples() == arguments.samples)
-                renderer.synchronize();  // render() only queues work; keep the progress line honest
-            progress.show(renderer.samples());
-        }
-        renderer.synchronize();
-        progress.finish();
-        const double renderSeconds = secondsSince(renderStart);
-        phase("Writing " + arguments.output->string(), [&] {
-            if (arguments.output->extension() == ".exr")
-                rt::writeExr(*arguments.output, width, height, renderer.linearPixels());
-            else
-                rt::writePng(*arguments.output, width, height, renderer.pixels());
-        });
-        std::uint64_t statistics[8] = {};
-        renderer.statistics(statistics);
-        const double rays = static_cast<double>(statistics[0] + statistics[1]);
-        std::cout << "Done at " << renderer.samples() << " spp\n"
-                  << "  " << std::fixed << std::setprecision(1) << rays / std::max(renderSeconds, 1e-9) / 1e6 << " Mrays/s ("
-                  << statistics[0] << " closest-hit + " << statistics[1] << " shadow rays in " << std::setprecision(2)
-                  << renderSeconds << " s)";
-        if (statistics[2])
-            std::cout << ", " << std::setprecision(1) << static_cast<double>(statistics[2]) / std::max(renderSeconds, 1e-9) / 1e6
-                      << " M photon gathers/s";
-        std::cout << '\n';
-        return 0;
+        return run(argc, argv);
     } catch (const std::exception& error) {
-        std::cerr << "error: " << error.what() << '\n';
+        std::fflush(stdout);
+        std::fprintf(stderr, "error: %s\n", error.what());
         return 1;
     }
 }
