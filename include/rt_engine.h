@@ -63,6 +63,23 @@ rt_status rt_build_photon_grid_async(const rt_photon* photons, uint32_t count, f
                                      uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes,
                                      rt_photon* sorted, void* stream);
 
+/* rt_build_photon_grid_async for callers that cannot allocate device memory
+ * (code under HIP graph capture, serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  The sort's scratch is a
+ * static device array inside the library (about 16.2 MiB per GPU, held until
+ * the process ends) sized for RT_PHOTON_GRID_STATIC_MAX_PHOTONS photons; a
+ * larger count returns RT_ERROR_OUT_OF_RANGE.  The call allocates and frees
+ * nothing.  Same results as rt_build_photon_grid_async (offsets: bucketCount
+ * + 1 uint32, sorted: count photons, both caller-owned device memory; the
+ * reference's `counts` array, which nothing reads, is not asked for).  The
+ * first call on a device looks the array's address up: make it outside a
+ * graph capture (count = 0 does).  Every call on a GPU shares that GPU's
+ * array: calls that overlap in time on one GPU (two streams, two host
+ * threads) race and must be ordered by the caller. */
+#define RT_PHOTON_GRID_STATIC_MAX_PHOTONS (1u << 20)
+rt_status rt_build_photon_grid_static(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                                      uint32_t* offsets, rt_photon* sorted, void* stream);
+
 /* photonBucket(photonCell(p, cellSize), bucketCount) for n packed float3
  * device positions (src/photon_hash.cuh:10-24) -> keys (device, n uint32). */
 rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uint32_t bucketCount, uint32_t* keys,

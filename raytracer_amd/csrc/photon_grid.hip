@@ -133,7 +133,7 @@ struct GridScratch {
     uint32_t* partials;
 };
 
-size_t scratchBytes(uint32_t maxCount, uint32_t bucketCount) {
+constexpr size_t scratchBytes(uint32_t maxCount, uint32_t bucketCount) {
     (void)bucketCount;
     const size_t n = alignUp(static_cast<size_t>(maxCount) * sizeof(uint32_t), 256);
     const size_t table = alignUp(sortTableEntries(maxCount) * sizeof(uint32_t), 256);
@@ -183,6 +183,33 @@ rt_status ownedWorkspace(size_t bytes, void** out) {
         w.bytes = bytes;
     }
     *out = w.data;
+    return RT_SUCCESS;
+}
+
+// Scratch of the entry point that allocates nothing: a file-scope device array sized
+// for RT_PHOTON_GRID_STATIC_MAX_PHOTONS photons, one copy per GPU that loads the
+// library.  Host code only ever uses the address hipGetSymbolAddress reports for the
+// current device (the array's name is a host-side stand-in, not a device address).
+constexpr size_t kStaticScratchBytes = scratchBytes(RT_PHOTON_GRID_STATIC_MAX_PHOTONS, 1U);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+std::mutex staticScratchMutex;
+void* staticScratchAddress[64];  // per device, filled by the first call on that device
+
+rt_status staticScratch(void** out) {
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64)
+        return failInvalid("device index");
+    std::lock_guard<std::mutex> lock(staticScratchMutex);
+    if (!staticScratchAddress[device]) {
+        void* address = nullptr;
+        RT_HIP(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
+        if (!address)
+            return failInvalid("the static photon-grid scratch has no device address");
+        staticScratchAddress[device] = address;
+    }
+    *out = staticScratchAddress[device];
     return RT_SUCCESS;
 }
 
@@ -256,6 +283,21 @@ rt_status rt_build_photon_grid(const rt_photon* photons, uint32_t count, float c
     RT_TRY(rt::buildGrid(photons, count, cellSize, bucketCount, counts, offsets, scan, scanBytes, sorted, nullptr));
     RT_HIP(hipDeviceSynchronize());
     return RT_SUCCESS;
+}
+
+rt_status rt_build_photon_grid_static(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
+                                      uint32_t* offsets, rt_photon* sorted, void* stream) {
+    if (count > RT_PHOTON_GRID_STATIC_MAX_PHOTONS) {
+        rt::setLastError("rt_build_photon_grid_static: " + std::to_string(count) + " photons exceed the static scratch, "
+                         "which holds RT_PHOTON_GRID_STATIC_MAX_PHOTONS = " +
+                         std::to_string(RT_PHOTON_GRID_STATIC_MAX_PHOTONS) + "; use rt_build_photon_grid_async");
+        return RT_ERROR_OUT_OF_RANGE;
+    }
+    void* workspace = nullptr;
+    RT_TRY(rt::staticScratch(&workspace));
+    // every word of the scratch the sort reads it has written first, so nothing of the last call's contents matters
+    return rt::buildGrid(photons, count, cellSize, bucketCount, nullptr, offsets, workspace, rt::kStaticScratchBytes,
+                         sorted, static_cast<hipStream_t>(stream));
 }
 
 rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uint32_t bucketCount, uint32_t* keys,

@@ -47,6 +47,7 @@ SYMBOLS = {
     "rt_photon_scan_storage": (_sz, [_u32]),
     "rt_build_photon_grid": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "rt_build_photon_grid_async": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "rt_build_photon_grid_static": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp]),
     "rt_photon_keys": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp]),
     "rt_photon_gather": (C.c_int, [_vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, _vp]),
     "rt_blas_build": (C.c_int, [_vp, _u32, _u32, _vp, _u32, _vp, C.POINTER(_vp)]),
@@ -127,6 +128,7 @@ def _stream(stream):
 
 
 PHOTON_FLOATS = 9  # rt_photon: position, power, normal
+STATIC_GRID_MAX_PHOTONS = 1 << 20  # RT_PHOTON_GRID_STATIC_MAX_PHOTONS
 
 
 def photon_keys(positions, cell_size, bucket_count, stream=None):
@@ -177,6 +179,17 @@ class PhotonGrid:
             check(lib.rt_build_photon_grid(*args))
         else:
             check(lib.rt_build_photon_grid_async(*args, _stream(stream)))
+        self.count = n
+        self.cell_size = float(cell_size)
+
+    def build_static(self, photons, cell_size, stream=None):
+        """rt_build_photon_grid_static: the build through the library's static scratch (allocates nothing)."""
+        import torch
+        assert photons.is_cuda and photons.dtype == torch.float32 and photons.is_contiguous()
+        n = photons.shape[0]
+        assert n <= self.capacity
+        check(load().rt_build_photon_grid_static(_ptr(photons), n, float(cell_size), self.bucket_count,
+                                                 _ptr(self.offsets), _ptr(self.sorted), _stream(stream)))
         self.count = n
         self.cell_size = float(cell_size)
 
