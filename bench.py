@@ -14,11 +14,16 @@ and gathered once per step count for the second metric (photon gathers/s, grid b
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch with torch.distributed.run, one rank per GPU: every rank holds a replica of the
-scene and renders the frame for its own sample indices (rank, rank + N, ...) - weak scaling, no
-collective on the data path.
+For N > 1 launch with torch.distributed.run, one rank per GPU over RCCL: every rank holds a replica of
+the scene and the N ranks share each frame (strong scaling of one frame): the bands of eight pixel rows
+are dealt out in turn (band b to rank b mod N), so a step is still one sample of every pixel of the
+frame; in the final profile every rank traces its share of the photon emissions and the lists are
+exchanged rank to rank into every rank's photon buffer before each rebuilds the same grid.  The bands
+are all-gathered once after the timed steps (reported as tile_allgather_ms).  N = 1 runs the plain
+single-GPU renderer.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -45,6 +50,9 @@ def parse():
     p.add_argument("--photons", type=int, default=1 << 23)
     p.add_argument("--tiles", type=int, default=3,
                    help="concurrent parts of the frame per render() call (1 = one stream)")
+    p.add_argument("--shared", action="store_true",
+                   help="run the multi-GPU code path (process group, dealt-out bands, photon exchange) with however "
+                        "many ranks there are, one included: a rehearsal of the N > 1 path on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-photon-bench", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -62,7 +70,7 @@ def make_scene(name):
     return workloads.caustic_lab(), 1
 
 
-def photon_benchmark(eng, workloads, args, rank, steps):
+def photon_benchmark(eng, workloads, args, rank, steps, cpu_seconds=0.0):
     """Grid build + gather over the reference-size photon map; queries are one per pixel of a frame
     looking at the table (row-major, so neighbouring lanes query neighbouring cells)."""
     import torch
@@ -95,7 +103,9 @@ def photon_benchmark(eng, workloads, args, rank, steps):
     build_ms = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
     gather_ms = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
     gather_bytes = 36.0 + 27.0 * 8.0 + 36.0 * per_query  # query in + flux out, 27 cell ranges, photons read
+    cpu = cpu_gather_baseline(grid, qp, qn, radius, buckets, cpu_seconds) if cpu_seconds > 0.0 else None
     return {
+        "cpu_baseline": cpu,
         "photons": n_ph, "buckets": buckets, "queries": int(qp.shape[0]), "radius": radius,
         "photons_read_per_query": per_query,
         "gathers_per_s": qp.shape[0] / (gather_ms * 1e-3),
@@ -108,20 +118,67 @@ def photon_benchmark(eng, workloads, args, rank, steps):
     }
 
 
+def library_hash():
+    from raytracer_amd import engine as eng
+    with open(eng.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def profiled_traffic():
-    """HBM bytes per trace launch from the newest committed rocprofv3 PMC summary (profiles/*_bench_summary.txt:
-    FETCH_SIZE x2-corrected plus WRITE_SIZE, separate --pmc passes of this same command), or None."""
+    """HBM bytes per trace launch (FETCH_SIZE x2-corrected plus WRITE_SIZE, separate rocprofv3 --pmc passes of
+    this same command) from the committed summary that was taken with the very library this run loads
+    (profiles/*_bench_summary.txt record the sha256 of librt_engine.so), or None when no summary matches:
+    a number measured on other kernels would be stale."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_summary.txt"))):
-        for line in open(path):
+    current = library_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_summary.txt")), reverse=True):
+        lines = open(path).read().splitlines()
+        if not any(line.startswith("librt_engine.so sha256") and current in line for line in lines):
+            continue
+        for line in lines:
             f = line.split()
             if len(f) >= 6 and f[0].startswith("traceKernel<false>"):
                 try:
-                    best = (float(f[3]) * 1e6 + float(f[4]) * 1024.0, os.path.basename(path))  # fetch_x2_MB, WRITE_KiB
+                    return float(f[3]) * 1e6 + float(f[4]) * 1024.0, os.path.basename(path)  # fetch_x2_MB, WRITE_KiB
                 except ValueError:
                     pass
-    return best
+    return None
+
+
+def copy_ceiling_gbs():
+    """What a plain device-to-device copy of 1 GiB reaches on this GPU, read + write bytes per second: the
+    achievable ceiling to read next to the 8 TB/s specification."""
+    import torch
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    dst.copy_(src)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(8):
+        dst.copy_(src)
+    stop.record()
+    torch.cuda.synchronize()
+    return 8 * 2.0 * n / (start.elapsed_time(stop) * 1e-3) / 1e9
+
+
+def host_cpu():
+    """(model name, threads this process may use): the affinity mask, cut to the pool's per-GPU share when the
+    environment states one (OMP_NUM_THREADS)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    threads = min(allowed, int(share)) if share.isdigit() and int(share) > 0 else allowed
+    return model, allowed, threads
 
 
 def cpu_baseline(scene, args, width, height, profile):
@@ -136,7 +193,7 @@ def cpu_baseline(scene, args, width, height, profile):
     for gi, m in scene["instances"]:
         ref.add_instance(gi, m)
     ref.commit()
-    threads = min(16, os.cpu_count() or 1)
+    model, allowed, threads = host_cpu()
     setup = Setup(scene, width, height, final=False)  # preview path lengths; no photon map on the CPU leg
     setup.params.sample = 0
     # probe: one sample of the middle half of the frame; then as many further samples of the same
@@ -156,17 +213,44 @@ def cpu_baseline(scene, args, width, height, profile):
     cpu_s = time.perf_counter() - t1
     rays = orc.ray_counter(reset=True)
     return {
-        "value": rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "value": rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu_model": model,
+        "hardware_threads_visible": allowed,
         "sample": f"{samples} samples of {rows} pixel rows ({samples * rows * width} paths, {rays} rays) from the middle "
                   f"of the same frame, preview depth, the oracle's integrator over its own BVH, {threads} std::thread "
-                  f"workers, {cpu_s:.1f} s (probe: {probe_rays} rays in {probe_s:.2f} s)",
+                  f"workers ({allowed} hardware threads visible, {threads} this job may use), {cpu_s:.1f} s "
+                  f"(probe: {probe_rays} rays in {probe_s:.2f} s)",
     }
+
+
+def cpu_gather_baseline(grid, qp, qn, radius, buckets, seconds):
+    """The oracle's causticLighting loop (device.cu:722-766 restated) over the GPU-built grid of the photon
+    benchmark, on every k-th query of the same query set, timed on the host threads."""
+    from oracle import binding as orc  # the CPU baseline leg: the oracle, timed, never shipped
+    model, allowed, threads = host_cpu()
+    srt = grid.sorted.cpu().numpy()
+    off = grid.offsets.cpu().numpy().view(np.uint32)
+    qp, qn = qp.cpu().numpy(), qn.cpu().numpy()
+    probe = slice(0, None, max(1, qp.shape[0] // 16384))
+    t1 = time.perf_counter()
+    orc.photon_gather(srt, off, buckets, radius, qp[probe], qn[probe], threads=threads)
+    probe_s = time.perf_counter() - t1
+    per_query = probe_s / max(len(qp[probe]), 1)
+    stride = max(1, int(qp.shape[0] * per_query / max(seconds, 0.1)))
+    pick = slice(0, None, stride)
+    t1 = time.perf_counter()
+    orc.photon_gather(srt, off, buckets, radius, qp[pick], qn[pick], threads=threads)
+    cpu_s = time.perf_counter() - t1
+    n = len(qp[pick])
+    return {"value": n / cpu_s, "unit": "gathers/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "sample": f"every {stride}th of the benchmark's {qp.shape[0]} queries ({n}) against the same "
+                      f"{srt.shape[0]}-photon grid, the oracle's gather loop on {threads} std::thread workers, {cpu_s:.2f} s"}
 
 
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    from raytracer_amd import distributed as D
     from raytracer_amd import engine as eng
     from raytracer_amd import renderer as R
     from raytracer_amd import workloads
@@ -177,41 +261,59 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > 1 or args.shared:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     R.load()
 
     scene, profile = make_scene(args.workload)
-    renderer = R.Renderer(scene, args.width, args.height, profile)
-    renderer.set_sample_sequence(rank, world)
-    if profile == R.FINAL:
-        renderer.set_photon_budget(1 << 24, 1 << 23, 1 << 22)
+    budget = (1 << 24, 1 << 23, 1 << 22) if profile == R.FINAL else None
+    if world > 1 or args.shared:
+        # the ranks share every frame: bands of eight rows dealt out in turn, emission ranges per rank
+        shared = D.DistributedRenderer(scene, args.width, args.height, profile, photon_budget=budget)
+        renderer = shared.renderer
+        step = shared.render
+    else:
+        shared = None
+        renderer = R.Renderer(scene, args.width, args.height, profile)
+        if budget:
+            renderer.set_photon_budget(*budget)
+        step = renderer.render
 
     # traversal averages per ray (for the algorithmic byte count), outside the timed region
     if profile == R.FINAL:
         # sample 0 starts with a photon pass, whose rays the traversal counters do not see
-        renderer.render()
+        step()
         renderer.statistics()
     renderer.set_measurement(count_traversal=True)
-    renderer.render()
+    step()
     c = renderer.statistics()
-    counted_rays = max(c["extend_rays"] + c["shadow_rays"], 1)
-    nodes_per_ray = c["nodes"] / counted_rays
-    tris_per_ray = c["triangles"] / counted_rays
+    counted = np.array([c["extend_rays"] + c["shadow_rays"], c["nodes"], c["triangles"]], dtype=np.float64)
+    if world > 1:
+        t = torch.from_numpy(counted).cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        counted = t.cpu().numpy()
+    counted_rays = max(counted[0], 1.0)
+    nodes_per_ray = counted[1] / counted_rays
+    tris_per_ray = counted[2] / counted_rays
     bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
     renderer.set_concurrent_tiles(args.tiles)
     renderer.set_measurement(time_stages=False)
     for _ in range(args.warmup):
-        renderer.render()
+        step()
     renderer.synchronize()
     renderer.statistics()
+    if shared:
+        shared.exchanges.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        renderer.render()
+        step()
     renderer.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -219,44 +321,67 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = renderer.statistics()
     rays = float(stats["extend_rays"] + stats["shadow_rays"])
+    exchanges = list(shared.exchanges) if shared else []
+
+    # once per image, not per sample: the bands of every rank into the full frame
+    tile_allgather_ms = None
+    if shared:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        frame = shared.gather_buffer(0)
+        torch.cuda.synchronize()
+        tile_allgather_ms = (time.perf_counter() - t1) * 1e3
+        assert frame.shape == (args.height, args.width, 4)
 
     # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
     # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
     # bracketed by HIP events on the stream it runs on.
     renderer.set_concurrent_tiles(1)
     renderer.set_measurement(time_stages=True)
-    renderer.render()
+    step()
     renderer.stage_timings()
     renderer.statistics()
     for _ in range(args.steps):
-        renderer.render()
+        step()
     renderer.synchronize()
     stages = renderer.stage_timings()
     staged = renderer.statistics()
     staged_rays = float(staged["extend_rays"] + staged["shadow_rays"])
+    per_rank = [rays]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        total = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        total_rays, total_gathers = float(total[0].item()), float(total[1].item())
+        mine = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(e[0].item()) for e in every]
+        total_rays, total_gathers = sum(per_rank), sum(float(e[1].item()) for e in every)
     else:
         total_rays, total_gathers = rays, float(stats["gather_queries"])
 
     photon = None
     if not args.no_photon_bench:
-        photon = photon_benchmark(eng, workloads, args, rank, max(3, min(args.steps, 10)))
+        cpu_seconds = 3.0 if (not args.no_cpu_baseline and world == 1) else 0.0
+        photon = photon_benchmark(eng, workloads, args, rank, max(3, min(args.steps, 10)), cpu_seconds)
+    ceiling = copy_ceiling_gbs() if rank == 0 else None
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     trace_ms, trace_launches = stages["trace"]
-    traffic = profiled_traffic() if args.workload == "dragon-cornell" and (args.width, args.height) == (1920, 1080) else None
+    traffic = profiled_traffic() if (args.workload == "dragon-cornell" and (args.width, args.height) == (1920, 1080)
+                                     and world == 1) else None
     achieved = staged_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
+    avg_launch_s = trace_ms * 1e-3 / max(trace_launches, 1)
     p = renderer.launch_params()
+    if shared:
+        parallelism = (f"replicated scene; one frame shared by {world} ranks, bands of 8 pixel rows dealt out in turn"
+                       + ("; photon emission ranges per rank, lists exchanged rank to rank over RCCL every 4th step"
+                          if profile else "; no collective inside a step"))
+    else:
+        parallelism = "one GPU"
     out = {
         "metric": "closest_hit_mrays_per_s",
         "value": total_rays / elapsed / 1e6,
@@ -266,7 +391,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -274,13 +399,14 @@ def main():
             "workload": f"{args.workload} stand-in, {args.width}x{args.height}, 1 sample per pixel per step, "
                         f"{'final (32 bounces, photon map)' if profile else 'preview (5 bounces)'}, wavefront "
                         f"generate/trace/shade/accumulate through rt::Renderer::render()",
+            "rays_per_step": total_rays / args.steps,
             "rays_per_step_per_gpu": rays / args.steps,
             "extend_rays_per_step": stats["extend_rays"] / args.steps,
             "shadow_rays_per_step": stats["shadow_rays"] / args.steps,
             "triangles": int(sum(scene["geometries"][g]["indices"].shape[0] for g, _ in scene["instances"])),
             "instances": len(scene["instances"]),
             "light_count": int(p.lightCount),
-            "parallelism": f"replicated scene, {world} x sample-index shards, no data-path collective",
+            "parallelism": parallelism,
         },
         "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
@@ -294,23 +420,45 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic[0] if traffic else None,
-            "traffic_source": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {traffic[1]}"
-                               if traffic else None),
+            "traffic_source": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {traffic[1]}, taken with "
+                               f"the library this run loaded" if traffic else
+                               "no committed PMC summary was taken with the library this run loaded"),
+            "traffic_gbs": traffic[0] / avg_launch_s / 1e9 if traffic else None,
+            "traffic_frac_of_peak": traffic[0] / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+            "copy_ceiling_gbs": ceiling,
+            "frac_of_copy_ceiling": achieved / ceiling if ceiling else None,
             "algorithmic_bytes_per_launch": staged_rays * bytes_per_ray / max(trace_launches, 1),
             "bytes_per_ray": bytes_per_ray,
             "nodes_per_ray": nodes_per_ray,
             "triangles_per_ray": tris_per_ray,
             "avg_launch_ms": trace_ms / max(trace_launches, 1),
             "launches": trace_launches,
+            "library_sha256": library_hash(),
         },
     }
+    if shared:
+        mean = sum(per_rank) / world
+        out["multi_gpu"] = {
+            "rays_per_rank": per_rank,
+            "imbalance_max_over_mean": max(per_rank) / mean if mean else None,
+            "tile_allgather_ms": tile_allgather_ms,
+            "tile_allgather_bytes": args.width * args.height * 16,
+            "photon_exchanges": len(exchanges),
+            "photon_allgather_ms": float(np.mean([e["ms"] for e in exchanges])) if exchanges else None,
+            "photon_allgather_bytes_received": float(np.mean([e["bytes_received"] for e in exchanges])) if exchanges else None,
+            "photons_per_pass": float(np.mean([e["photons"] for e in exchanges])) if exchanges else None,
+        }
     if photon is not None:
         out["photon_gathers_per_s"] = photon["gathers_per_s"]
         out["photon"] = photon
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(scene, args, args.width, args.height, profile)
+        if photon is not None and photon.get("cpu_baseline"):
+            out["cpu_baseline"]["gather"] = photon.pop("cpu_baseline")
+    if photon is not None:
+        photon.pop("cpu_baseline", None)
     print(json.dumps(out))
-    if world > 1:
+    if shared:
         dist.destroy_process_group()
 
 

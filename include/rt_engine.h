@@ -228,6 +228,19 @@ rt_status rt_render_sample(rt_wavefront* wavefront, const rt_launch_params* para
 rt_status rt_render_sample_seeded(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t pixelBegin,
                                   uint32_t pixelEnd, uint32_t seedSample, void* stream);
 
+/* One camera sample for every bandStride-th band of eight pixel rows, starting
+ * with band firstBand (rows 8 * firstBand ..), bandCount bands at most; bands
+ * beyond the image are left out and the last band of an image whose height is
+ * no multiple of 8 is shorter.  With bandStride = 1 this is a contiguous block
+ * of rows; with bandStride = N and firstBand = r it is the share of GPU r of N
+ * when the bands of one frame are dealt out in turn (no counterpart upstream,
+ * which renders a frame with one launch, src/renderer.cpp:790-791).  A pixel's
+ * random streams depend on its own index and the sample only
+ * (src/device.cu:882), so the buffers equal those of rt_render_sample over the
+ * same pixels bit for bit.  The pixels covered must not exceed maxPaths. */
+rt_status rt_render_sample_bands(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstBand,
+                                 uint32_t bandStride, uint32_t bandCount, uint32_t seedSample, void* stream);
+
 /* The photon pass for emission indices [firstEmission, firstEmission +
  * emissionCount) of pass params->photonPass: photons are appended to
  * params->photons behind *params->photonCount in emission order (the reference

@@ -7,6 +7,7 @@ set -e
 TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+sha256sum raytracer_amd/librt_engine.so > $OUT/library.sha256
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --tiles 1"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1

@@ -27,6 +27,9 @@ def short(name):
 
 def main(root):
     lines = []
+    stamp = os.path.join(root, "library.sha256")
+    if os.path.exists(stamp):  # which build of the kernels these numbers belong to (bench.py matches it)
+        lines.append("librt_engine.so sha256 " + open(stamp).read().split()[0])
     for path in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
         lines.append("== kernel time (rocprofv3 --kernel-trace --stats) ==")
         lines.append(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")

@@ -115,26 +115,39 @@ __device__ inline void allocateSlotPair(bool wantA, uint32_t* counterA, bool wan
 
 // ---- camera paths -----------------------------------------------------------
 
-// Pixel of path i of a launch over [pixelBegin, pixelBegin + count).  Paths are
-// numbered tile by tile (8 x 8 pixels) over the full eight-row bands of the
-// range, so the 64 lanes of a wave hold a compact patch of the image: their rays
-// walk the same nodes and their photon queries the same cells.  Rows left over
-// at the end, and ranges that do not start on a row, keep row-major order.  Only
-// the numbering of paths changes; a pixel's random streams depend on its own index.
-__device__ inline uint32_t pixelOfPath(uint32_t i, uint32_t pixelBegin, uint32_t count, uint32_t width) {
-    if (pixelBegin % width != 0U || width % 8U != 0U)
-        return pixelBegin + i;
-    const uint32_t band = 8U * width;
-    if (i >= count / band * band)
-        return pixelBegin + i;
-    const uint32_t inBand = i % band, tile = inBand / 64U, within = inBand % 64U;
-    return pixelBegin + (i - inBand) + (within / 8U) * width + tile * 8U + within % 8U;
-}
+// Which pixels a launch covers and how its paths are numbered.  The pixels are a run of
+// bands of eight rows (every bandStride-th band of the image, so that several GPUs can
+// take the bands of one frame in turn) followed by a row-major tail: the rows of a last,
+// shorter band, or a whole range that does not start on a row.  Inside a full band the
+// paths are numbered tile by tile (8 x 8 pixels), so the 64 lanes of a wave hold a compact
+// patch of the image: their rays walk the same nodes and their photon queries the same
+// cells.  Only the numbering of paths changes; a pixel's random streams depend on its own
+// index.
+struct PixelMap {
+    uint32_t begin;       // first pixel of the first band
+    uint32_t count;       // paths of the launch
+    uint32_t width;       // image width
+    uint32_t bandPaths;   // paths in the tile-numbered bands (a multiple of 8 * width), then the tail
+    uint32_t bandStride;  // pixels from one band of the launch to the next (8 * width when contiguous)
+    uint32_t tailBegin;   // first pixel of the row-major tail
+    uint32_t tiled;       // 0 when the width is no multiple of 8: the bands then keep row-major order too
+
+    __device__ uint32_t pixel(uint32_t i) const {
+        if (i >= bandPaths)
+            return tailBegin + (i - bandPaths);
+        const uint32_t band = 8U * width;
+        const uint32_t k = i / band, inBand = i - k * band, tile = inBand / 64U, within = inBand % 64U;
+        if (!tiled)
+            return begin + k * bandStride + inBand;
+        return begin + k * bandStride + (within / 8U) * width + tile * 8U + within % 8U;
+    }
+};
 
 // device.cu:882-906: one path per pixel of [pixelBegin, pixelBegin + count)
-__global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p, uint32_t pixelBegin, uint32_t count,
-                                                              uint32_t seedSample, Buffers b) {
+__global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p, PixelMap map, uint32_t seedSample,
+                                                              Buffers b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count = map.count;
     if (i == 0) {
         b.counts[0] = count;
         b.counts[1] = 0;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     }
     if (i >= count)
         return;
-    const uint32_t index = pixelOfPath(i, pixelBegin, count, p.width);
+    const uint32_t index = map.pixel(i);
     const uint32_t px = index % p.width, py = index / p.width;
     uint32_t rng = index * 9781U + seedSample * 6271U + 0x68bc21ebU;
     const float jx = random01(rng);
@@ -622,12 +635,11 @@ __global__ void advanceKernel(Buffers b, int which) {
 }
 
 // device.cu:1043-1074: running means of the seven buffers and the tone-mapped byte image.
-__global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params p, uint32_t pixelBegin,
-                                                                uint32_t count, Buffers b) {
+__global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params p, PixelMap map, Buffers b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count)
+    if (i >= map.count)
         return;
-    const uint32_t index = pixelOfPath(i, pixelBegin, count, p.width);
+    const uint32_t index = map.pixel(i);
     const float weight = 1.0f / static_cast<float>(p.sample + 1U);
     const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
     const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
@@ -1084,23 +1096,10 @@ rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint
     return rt_render_sample_seeded(w, params, pixelBegin, pixelEnd, params->sample, stream);
 }
 
-rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin,
-                                  uint32_t pixelEnd, uint32_t seedSample, void* stream) {
-    const rt_scene* scene = nullptr;
-    RT_TRY(checkLaunch(w, params, scene));
-    if (pixelEnd < pixelBegin || pixelEnd > params->width * params->height)
-        return failInvalid("pixel range");
-    // a positive photon radius switches the caustic gather on; it reads these
-    if (params->photonRadius > 0.0f &&
-        (!params->sortedPhotons || !params->photonCellStart || params->photonBucketCount == 0 ||
-         (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
-        return failInvalid("photon radius set without a photon grid (sorted photons, cell starts, power-of-two bucket count)");
-    const uint32_t count = pixelEnd - pixelBegin;
-    if (count == 0)
-        return RT_SUCCESS;
-    if (count > w->buffers.capacity)
-        return failInvalid("pixel range larger than the wavefront capacity");
-    auto s = static_cast<hipStream_t>(stream);
+// One sample for the paths of `map` (its count is at least 1 and at most the capacity).
+static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, const rt_scene* scene, const PixelMap& map,
+                             uint32_t seedSample, hipStream_t s) {
+    const uint32_t count = map.count;
     const Buffers& b = w->buffers;
     const unsigned blocks = divUp(count, kShadeBlock);
     const unsigned resident = std::max<unsigned>(
@@ -1110,8 +1109,7 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
     {
         StageTimer timer(w, s, 0);
-        hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count,
-                           seedSample, b);
+        hipLaunchKernelGGL(generateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, map, seedSample, b);
     }
     const uint2 limits = limitsOf(scene);
     // stage 1 is the ray stage (traceKernel), stage 3 the bookkeeping between bounces
@@ -1149,10 +1147,78 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     }
     {
         StageTimer timer(w, s, 4);
-        hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, pixelBegin, count, b);
+        hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, map, b);
     }
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
+}
+
+// What both sample entry points check before anything is launched.
+static rt_status checkSample(rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
+    RT_TRY(checkLaunch(w, params, scene));
+    if (params->width == 0 || params->height == 0 ||
+        static_cast<uint64_t>(params->width) * params->height > 0xffffffffULL)
+        return failInvalid("image size");
+    // a positive photon radius switches the caustic gather on; it reads these
+    if (params->photonRadius > 0.0f &&
+        (!params->sortedPhotons || !params->photonCellStart || params->photonBucketCount == 0 ||
+         (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
+        return failInvalid("photon radius set without a photon grid (sorted photons, cell starts, power-of-two bucket count)");
+    return RT_SUCCESS;
+}
+
+rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* params, uint32_t pixelBegin,
+                                  uint32_t pixelEnd, uint32_t seedSample, void* stream) {
+    const rt_scene* scene = nullptr;
+    RT_TRY(checkSample(w, params, scene));
+    if (pixelEnd < pixelBegin || pixelEnd > params->width * params->height)
+        return failInvalid("pixel range");
+    const uint32_t count = pixelEnd - pixelBegin;
+    if (count == 0)
+        return RT_SUCCESS;
+    if (count > w->buffers.capacity)
+        return failInvalid("pixel range larger than the wavefront capacity");
+    const uint32_t width = params->width, band = 8U * width;
+    PixelMap map;
+    map.begin = pixelBegin;
+    map.count = count;
+    map.width = width;
+    // full bands first when the range starts on a row and rows split into 8-pixel tiles
+    map.bandPaths = (pixelBegin % width == 0U && width % 8U == 0U) ? count / band * band : 0U;
+    map.bandStride = band;
+    map.tailBegin = pixelBegin + map.bandPaths;
+    map.tiled = 1;
+    return renderPaths(w, params, scene, map, seedSample, static_cast<hipStream_t>(stream));
+}
+
+rt_status rt_render_sample_bands(rt_wavefront* w, const rt_launch_params* params, uint32_t firstBand,
+                                 uint32_t bandStride, uint32_t bandCount, uint32_t seedSample, void* stream) {
+    const rt_scene* scene = nullptr;
+    RT_TRY(checkSample(w, params, scene));
+    if (bandStride == 0)
+        return failInvalid("band stride is zero");
+    const uint32_t width = params->width, height = params->height;
+    const uint32_t bands = (height + 7U) / 8U;
+    if (bandCount == 0 || firstBand >= bands)
+        return RT_SUCCESS;
+    // the launch's bands: firstBand + k * bandStride below `bands`
+    const uint32_t covered = std::min<uint64_t>(bandCount, (static_cast<uint64_t>(bands - 1U - firstBand) / bandStride) + 1U);
+    const uint32_t lastBand = firstBand + (covered - 1U) * bandStride;
+    const uint32_t lastRows = std::min(8U, height - lastBand * 8U);
+    const uint32_t fullBands = lastRows == 8U ? covered : covered - 1U;
+    const uint64_t count = static_cast<uint64_t>(fullBands) * 8U * width + (lastRows == 8U ? 0U : lastRows * width);
+    if (count > w->buffers.capacity)
+        return failInvalid("bands larger than the wavefront capacity");
+    const uint32_t band = 8U * width;
+    PixelMap map;
+    map.begin = firstBand * band;
+    map.count = static_cast<uint32_t>(count);
+    map.width = width;
+    map.bandStride = bandStride * band;
+    map.tailBegin = lastBand * band;  // only used when the last band is short
+    map.bandPaths = fullBands * band;
+    map.tiled = width % 8U == 0U ? 1U : 0U;
+    return renderPaths(w, params, scene, map, seedSample, static_cast<hipStream_t>(stream));
 }
 
 rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint32_t firstEmission,

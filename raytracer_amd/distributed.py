@@ -1,18 +1,25 @@
-"""Multi-GPU driver: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" for
-the CPU tests of the exchange logic).
+"""Multi-GPU driver: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" for the CPU tests of the exchange logic and for several processes on one card).
 
 What shards (the reference itself is single-GPU; this is new work):
-  * camera paths by image rows - a pixel's whole sample sequence stays on one GPU, and the random
-    streams depend only on (pixel, sample) (device.cu:882), so a tile is bit-identical to the same
-    pixels of a one-GPU render; one all-gather of the float4 tiles when the image is read;
+  * camera paths by bands of eight pixel rows dealt out in turn - band b belongs to rank b mod N, so
+    rows that are dear to trace (the mesh in the middle of the frame) spread over all ranks where
+    contiguous blocks would leave them with one or two; a pixel's whole sample sequence stays on one
+    GPU and the random streams depend only on (pixel, sample) (device.cu:882), so a rank's bands are
+    bit-identical to the same pixels of a one-GPU render; the bands are all-gathered once, when the
+    image is read;
   * photon emission by emission-index ranges - photon i's stream is seeded(i, pass) (device.cu:772)
-    whoever traces it; every rank's list is in emission order, so concatenating the lists in rank order
-    gives the one-GPU list, and every rank then builds the same hash grid locally.
+    whoever traces it; every rank's list is in emission order, so laying the lists out in rank order
+    gives the one-GPU list, and every rank then builds the same hash grid locally.  The exchange is
+    two steps: the counts (N x 8 bytes, all-gather), then each rank sends its list once to every
+    peer and receives every peer's list at its final offset in the photon buffer, all transfers of a
+    pass in one group (direct sends over the point-to-point links; no ring, no staging copy).
 The BVH is replicated (built deterministically on every GPU); there is no collective on ray traversal.
 """
-import ctypes as C
+import time
 
-import numpy as np
+BAND_ROWS = 8        # rows per band of a frame (the engine numbers paths in 8 x 8 tiles)
+PHOTON_FLOATS = 9    # rt_photon: position, power, normal
 
 
 def shard_range(total, rank, world):
@@ -20,100 +27,161 @@ def shard_range(total, rank, world):
     return total * rank // world, total * (rank + 1) // world
 
 
-def row_range(height, width, rank, world):
-    """Pixel range of the rows owned by `rank` (row-major, row 0 at the bottom as in the reference)."""
-    r0, r1 = shard_range(height, rank, world)
-    return r0 * width, r1 * width
+def band_count(height):
+    return (height + BAND_ROWS - 1) // BAND_ROWS
+
+
+def owned_bands(height, rank, world):
+    """Bands of eight rows that `rank` renders: rank, rank + world, ..."""
+    return range(rank, band_count(height), world)
+
+
+def _backend_device(tensor, group):
+    """The tensor where the group's backend can reach it: gloo moves host memory, RCCL device memory."""
+    import torch.distributed as dist
+    return tensor.cpu() if dist.get_backend(group) == "gloo" else tensor
+
+
+def gather_counts(count, group=None, device="cpu"):
+    """All-gathers one integer per rank; returns the list in rank order."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(count)], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    return [int(c.item()) for c in every]
+
+
+def photon_slots(counts, capacity):
+    """Where each rank's photons go in the merged list: (offset, kept) per rank, the list cut at `capacity`."""
+    slots, offset = [], 0
+    for c in counts:
+        kept = max(0, min(c, capacity - offset))
+        slots.append((offset, kept))
+        offset += c
+    return slots
+
+
+def exchange_photons_into(dest, mine, counts, group=None):
+    """Places every rank's photon list at its rank-ordered offset in `dest`.
+
+    dest: (capacity, 9) float32, the merged list (on the device the backend reaches); mine: this rank's
+    photons in emission order, at least counts[rank] rows; counts: gather_counts() of the list lengths.
+    One grouped exchange: this rank's rows go once to every peer, every peer's rows arrive at their final
+    place; the own rows are a local copy.  Returns (rows kept in dest, bytes sent, bytes received)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    slots = photon_slots(counts, dest.shape[0])
+    offset, kept = slots[rank]
+    if kept:
+        dest[offset:offset + kept].copy_(mine[:kept])
+    ops = []
+    sent = received = 0
+    for peer in range(world):
+        if peer == rank:
+            continue
+        if kept:
+            ops.append(dist.P2POp(dist.isend, mine[:kept], peer, group))
+            sent += kept * PHOTON_FLOATS * 4
+        peer_offset, peer_kept = slots[peer]
+        if peer_kept:
+            ops.append(dist.P2POp(dist.irecv, dest[peer_offset:peer_offset + peer_kept], peer, group))
+            received += peer_kept * PHOTON_FLOATS * 4
+    if ops:
+        for request in dist.batch_isend_irecv(ops):
+            request.wait()
+    return sum(k for _, k in slots), sent, received
 
 
 def exchange_photons(local, capacity, group=None):
-    """All-gathers per-rank photon lists (n_i, 9) float32 into the rank-ordered concatenation, clamped
-    to `capacity` rows.  Returns (merged tensor on local.device, total count before clamping).
-
-    Two collectives: the 4-byte counts, then the payload padded to the largest count (each rank's slab
-    goes out once to every peer; on an xGMI mesh that is one direct transfer per link pair)."""
+    """All-gathers per-rank photon lists (n_i, 9) float32 into the rank-ordered concatenation, cut at
+    `capacity` rows.  Returns (merged tensor on local.device, total count before the cut)."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
     home = local.device
-    if dist.get_backend(group) == "gloo":
-        local = local.cpu()  # gloo moves host memory; RCCL takes the device tensors as they are
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    widest = max(max(counts), 1)
-    padded = torch.zeros((widest, 9), dtype=torch.float32, device=local.device)
-    padded[: local.shape[0]] = local
-    slabs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(slabs, padded, group=group)
-    merged = torch.cat([s[:c] for s, c in zip(slabs, counts)], dim=0)
+    local = _backend_device(local.contiguous(), group)
+    counts = gather_counts(local.shape[0], group, local.device)
     total = sum(counts)
-    return merged[:capacity].contiguous().to(home), total
+    merged = torch.empty((min(total, capacity), PHOTON_FLOATS), dtype=torch.float32, device=local.device)
+    exchange_photons_into(merged, local, counts, group)
+    return merged.to(home), total
 
 
-def gather_rows(local_rows, height, group=None):
-    """All-gathers row tiles (rows_i, width, channels) owned per shard_range(height, rank, world) into the
-    full (height, width, channels) image on every rank."""
+def gather_bands(mine, height, group=None):
+    """All-gathers the bands every rank owns into the full frame.
+
+    mine: (bands owned, elements per band) tensor of this rank's bands in ascending order (a last, shorter
+    band of the frame padded to full size).  Returns (band_count(height), elements per band) on mine.device,
+    band b taken from rank b mod N."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    home = local_rows.device
-    if dist.get_backend(group) == "gloo":
-        local_rows = local_rows.cpu()
-    sizes = [shard_range(height, r, world) for r in range(world)]
-    widest = max(e - b for b, e in sizes)
-    padded = torch.zeros((widest,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
-    padded[: local_rows.shape[0]] = local_rows
+    home = mine.device
+    mine = _backend_device(mine.contiguous(), group)
+    bands = band_count(height)
+    widest = len(owned_bands(height, 0, world))
+    padded = mine
+    if mine.shape[0] < widest:
+        padded = torch.zeros((widest, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+        padded[: mine.shape[0]] = mine
     slabs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(slabs, padded, group=group)
-    return torch.cat([s[: e - b] for s, (b, e) in zip(slabs, sizes)], dim=0).to(home)
-
-
-def _hip():
-    return C.CDLL("libamdhip64.so")
-
-
-def _copy(dst_ptr, src_ptr, nbytes, kind=3):  # hipMemcpyDeviceToDevice
-    if nbytes:
-        status = _hip().hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes), C.c_int(kind))
-        if status != 0:
-            raise RuntimeError(f"hipMemcpy failed with {status}")
+    full = torch.empty((bands, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+    for r in range(world):
+        own = owned_bands(height, r, world)
+        full[r::world] = slabs[r][: len(own)]
+    return full.to(home)
 
 
 class DistributedRenderer:
     """rt::Renderer sharded over the ranks of a process group.  Same calls as the single-GPU class:
     render(), linear_pixels(), samples()."""
 
-    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None):
+    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None):
         import torch
         import torch.distributed as dist
         from . import renderer as R
+        self.R = R
+        self.torch = torch
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) != "gloo"  # RCCL sends from and receives into device memory
         self.width, self.height = width, height
         self.renderer = R.Renderer(scene, width, height, profile)
         if photon_budget is not None:
             self.renderer.set_photon_budget(*photon_budget)
+        if tiles is not None:
+            self.renderer.set_concurrent_tiles(tiles)
         self.renderer.set_manual_photon_passes(True)
-        self.pixel_begin, self.pixel_end = row_range(height, width, self.rank, self.world)
-        self.renderer.set_pixel_range(self.pixel_begin, self.pixel_end)
-        self.torch = torch
+        self.renderer.set_row_interleave(self.rank, self.world)
+        self.exchanges = []  # per photon pass: dict(ms, photons, kept, bytes_sent, bytes_received)
 
     def _photon_pass(self):
-        torch = self.torch
-        r = self.renderer
+        torch, r, R = self.torch, self.renderer, self.R
         first, last = shard_range(r.photon_emissions(), self.rank, self.world)
+        capacity = r.photon_capacity()
         r.begin_photon_pass()
-        stored = r.trace_photon_range(first, last - first)
-        local = torch.empty((stored, 9), dtype=torch.float32, device="cuda")
-        _copy(local.data_ptr(), r.photon_buffer(), stored * 36)
-        merged, total = exchange_photons(local, r.photon_capacity(), self.group)
-        torch.cuda.synchronize()
-        _copy(r.photon_buffer(), merged.data_ptr(), merged.shape[0] * 36)
-        r.finish_photon_pass(merged.shape[0])
-        return total
+        # the local list goes to the staging area, so that every list, this rank's too, can be placed at
+        # its final offset of the photon buffer without a copy through a third buffer
+        stored = r.trace_photon_range(first, last - first, staging=True)
+        t0 = time.perf_counter()
+        staging = R.device_view(r.photon_staging_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
+        dest = R.device_view(r.photon_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
+        if self.on_device:
+            counts = gather_counts(stored, self.group, "cuda")
+            kept, sent, received = exchange_photons_into(dest, staging, counts, self.group)
+            torch.cuda.current_stream().synchronize()  # the pass is timed; the grid build would order itself
+        else:
+            counts = gather_counts(stored, self.group, "cpu")
+            host = torch.empty((min(sum(counts), capacity), PHOTON_FLOATS), dtype=torch.float32)
+            kept, sent, received = exchange_photons_into(host, staging[:stored].cpu(), counts, self.group)
+            dest[:kept].copy_(host[:kept])
+            torch.cuda.synchronize()
+        self.exchanges.append(dict(ms=(time.perf_counter() - t0) * 1e3, photons=sum(counts), kept=kept,
+                                   bytes_sent=sent, bytes_received=received))
+        r.finish_photon_pass(kept)
+        return sum(counts)
 
     def render(self):
         if self.renderer.photon_pass_due():
@@ -123,12 +191,28 @@ class DistributedRenderer:
     def samples(self):
         return self.renderer.samples()
 
-    def linear_pixels(self):
-        """The full accumulation image on every rank (tiles all-gathered)."""
-        torch = self.torch
+    def statistics(self):
+        return self.renderer.statistics()
+
+    def synchronize(self):
         self.renderer.synchronize()
-        r0, r1 = shard_range(self.height, self.rank, self.world)
-        rows = torch.empty((r1 - r0, self.width, 4), dtype=torch.float32, device="cuda")
-        base = self.renderer.accumulation_buffer(0) + self.pixel_begin * 16
-        _copy(rows.data_ptr(), base, rows.numel() * 4)
-        return gather_rows(rows, self.height, self.group).cpu().numpy()
+
+    def gather_buffer(self, index=0):
+        """Accumulation buffer `index` (0 = the image, 1..6 its layers) of the whole frame on every rank, as a
+        (height, width, 4) float32 tensor: the bands all-gathered."""
+        torch, R = self.torch, self.R
+        self.renderer.synchronize()
+        bands = band_count(self.height)
+        per_band = BAND_ROWS * self.width * 4
+        frame = R.device_view(self.renderer.accumulation_buffer(index), self.height * self.width * 16, torch.float32)
+        padded = frame
+        if self.height % BAND_ROWS:
+            padded = torch.zeros(bands * per_band, dtype=torch.float32, device="cuda")
+            padded[: frame.numel()] = frame
+        mine = padded.view(bands, per_band)[self.rank::self.world]
+        full = gather_bands(mine, self.height, self.group)
+        return full.reshape(bands * BAND_ROWS, self.width, 4)[: self.height]
+
+    def linear_pixels(self):
+        """The full accumulation image on every rank, as the single-GPU class returns it."""
+        return self.gather_buffer(0).cpu().numpy()

@@ -56,94 +56,122 @@ void rth_scene_destroy(rt::Scene* scene) { delete scene; }
 
 // Material fields as laid out in rt_gpu_material (the scene.hpp:52-73 members).
 int rth_scene_add_material(rt::Scene* scene, const rt_gpu_material* m) {
-    rt::Material out;
-    out.baseColor = {m->baseColor.x, m->baseColor.y, m->baseColor.z, m->baseColor.w};
-    out.emissive = {m->emissive.x, m->emissive.y, m->emissive.z};
-    out.attenuationColor = {m->attenuationColor.x, m->attenuationColor.y, m->attenuationColor.z};
-    out.metallic = m->metallic;
-    out.roughness = m->roughness;
-    out.transmission = m->transmission;
-    out.ior = m->ior;
-    out.thickness = m->thickness;
-    out.attenuationDistance = m->attenuationDistance;
-    out.emissiveStrength = m->emissiveStrength;
-    out.dispersion = m->dispersion;
-    out.baseColorTexture = textureRef(m->baseColorTexture);
-    out.metallicRoughnessTexture = textureRef(m->metallicRoughnessTexture);
-    out.normalTexture = textureRef(m->normalTexture);
-    out.emissiveTexture = textureRef(m->emissiveTexture);
-    out.transmissionTexture = textureRef(m->transmissionTexture);
-    out.thicknessTexture = textureRef(m->thicknessTexture);
-    scene->materials.push_back(out);
-    return static_cast<int>(scene->materials.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Material out;
+        out.baseColor = {m->baseColor.x, m->baseColor.y, m->baseColor.z, m->baseColor.w};
+        out.emissive = {m->emissive.x, m->emissive.y, m->emissive.z};
+        out.attenuationColor = {m->attenuationColor.x, m->attenuationColor.y, m->attenuationColor.z};
+        out.metallic = m->metallic;
+        out.roughness = m->roughness;
+        out.transmission = m->transmission;
+        out.ior = m->ior;
+        out.thickness = m->thickness;
+        out.attenuationDistance = m->attenuationDistance;
+        out.emissiveStrength = m->emissiveStrength;
+        out.dispersion = m->dispersion;
+        out.baseColorTexture = textureRef(m->baseColorTexture);
+        out.metallicRoughnessTexture = textureRef(m->metallicRoughnessTexture);
+        out.normalTexture = textureRef(m->normalTexture);
+        out.emissiveTexture = textureRef(m->emissiveTexture);
+        out.transmissionTexture = textureRef(m->transmissionTexture);
+        out.thicknessTexture = textureRef(m->thicknessTexture);
+        scene->materials.push_back(out);
+        index = static_cast<int>(scene->materials.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_geometry(rt::Scene* scene, const rt_gpu_vertex* vertices, uint32_t vertexCount,
                            const uint32_t* indices, uint32_t triangleCount, uint32_t material) {
-    rt::Geometry g;
-    g.vertices.resize(vertexCount);
-    for (uint32_t i = 0; i < vertexCount; ++i) {
-        const rt_gpu_vertex& v = vertices[i];
-        g.vertices[i] = {{v.position.x, v.position.y, v.position.z},
-                         {v.normal.x, v.normal.y, v.normal.z},
-                         {v.tangent.x, v.tangent.y, v.tangent.z, v.tangent.w},
-                         {v.uv.x, v.uv.y},
-                         {v.uv1.x, v.uv1.y}};
-    }
-    g.indices.assign(indices, indices + 3 * static_cast<size_t>(triangleCount));
-    g.material = material;
-    scene->geometries.push_back(std::move(g));
-    return static_cast<int>(scene->geometries.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Geometry g;
+        g.vertices.resize(vertexCount);
+        for (uint32_t i = 0; i < vertexCount; ++i) {
+            const rt_gpu_vertex& v = vertices[i];
+            g.vertices[i] = {{v.position.x, v.position.y, v.position.z},
+                             {v.normal.x, v.normal.y, v.normal.z},
+                             {v.tangent.x, v.tangent.y, v.tangent.z, v.tangent.w},
+                             {v.uv.x, v.uv.y},
+                             {v.uv1.x, v.uv1.y}};
+        }
+        g.indices.assign(indices, indices + 3 * static_cast<size_t>(triangleCount));
+        g.material = material;
+        scene->geometries.push_back(std::move(g));
+        index = static_cast<int>(scene->geometries.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_instance(rt::Scene* scene, uint32_t geometry, const float* m16) {
-    scene->instances.push_back({"", matrix(m16), geometry});
-    return static_cast<int>(scene->instances.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        scene->instances.push_back({"", matrix(m16), geometry});
+        index = static_cast<int>(scene->instances.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_camera(rt::Scene* scene, const float* m16, float verticalFov, float aspectRatio, float nearPlane,
                          float aperture, float focusDistance) {
-    rt::Camera c;
-    c.transform = matrix(m16);
-    c.verticalFov = verticalFov;
-    c.aspectRatio = aspectRatio;
-    c.nearPlane = nearPlane;
-    c.aperture = aperture;
-    c.focusDistance = focusDistance;
-    scene->cameras.push_back(c);
-    return static_cast<int>(scene->cameras.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Camera c;
+        c.transform = matrix(m16);
+        c.verticalFov = verticalFov;
+        c.aspectRatio = aspectRatio;
+        c.nearPlane = nearPlane;
+        c.aperture = aperture;
+        c.focusDistance = focusDistance;
+        scene->cameras.push_back(c);
+        index = static_cast<int>(scene->cameras.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_light(rt::Scene* scene, const float* m16, const float* color3, float intensity, float range,
                         float innerCone, float outerCone, uint32_t type) {
-    rt::Light l;
-    l.transform = matrix(m16);
-    l.color = {color3[0], color3[1], color3[2]};
-    l.intensity = intensity;
-    l.range = range;
-    l.innerCone = innerCone;
-    l.outerCone = outerCone;
-    l.type = type;
-    scene->lights.push_back(l);
-    return static_cast<int>(scene->lights.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Light l;
+        l.transform = matrix(m16);
+        l.color = {color3[0], color3[1], color3[2]};
+        l.intensity = intensity;
+        l.range = range;
+        l.innerCone = innerCone;
+        l.outerCone = outerCone;
+        l.type = type;
+        scene->lights.push_back(l);
+        index = static_cast<int>(scene->lights.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_image(rt::Scene* scene, const uint8_t* rgba, uint32_t width, uint32_t height) {
-    rt::Image image;
-    image.rgba.assign(rgba, rgba + static_cast<size_t>(width) * height * 4);
-    image.width = width;
-    image.height = height;
-    scene->images.push_back(std::move(image));
-    return static_cast<int>(scene->images.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Image image;
+        image.rgba.assign(rgba, rgba + static_cast<size_t>(width) * height * 4);
+        image.width = width;
+        image.height = height;
+        scene->images.push_back(std::move(image));
+        index = static_cast<int>(scene->images.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 int rth_scene_add_texture(rt::Scene* scene, int32_t image, uint32_t wrapU, uint32_t wrapV) {
-    rt::Texture t;
-    t.image = image;
-    t.wrapU = wrapU;
-    t.wrapV = wrapV;
-    scene->textures.push_back(t);
-    return static_cast<int>(scene->textures.size()) - 1;
+    int index = -1;
+    const int status = guarded([&] {
+        rt::Texture t;
+        t.image = image;
+        t.wrapU = wrapU;
+        t.wrapV = wrapV;
+        scene->textures.push_back(t);
+        index = static_cast<int>(scene->textures.size()) - 1;
+    });
+    return status == 0 ? index : -1;
 }
 
 void rth_scene_set_environment(rt::Scene* scene, const float* rgba, uint32_t width, uint32_t height, float rotation,
@@ -396,6 +424,9 @@ int rth_renderer_set_sample_sequence(rt::Renderer* r, uint32_t first, uint32_t s
 int rth_renderer_set_pixel_range(rt::Renderer* r, uint32_t begin, uint32_t end) {
     return guarded([&] { r->setPixelRange(begin, end); });
 }
+int rth_renderer_set_row_interleave(rt::Renderer* r, uint32_t first, uint32_t stride) {
+    return guarded([&] { r->setRowInterleave(first, stride); });
+}
 int rth_renderer_set_concurrent_tiles(rt::Renderer* r, uint32_t count) {
     return guarded([&] { r->setConcurrentTiles(count); });
 }
@@ -406,10 +437,12 @@ int rth_renderer_set_ray_share(rt::Renderer* r, uint32_t numerator, uint32_t den
 void rth_renderer_set_manual_photon_passes(rt::Renderer* r, int manual) { r->setManualPhotonPasses(manual != 0); }
 int rth_renderer_photon_pass_due(rt::Renderer* r) { return r->photonPassDue() ? 1 : 0; }
 int rth_renderer_begin_photon_pass(rt::Renderer* r) { return guarded([&] { r->beginPhotonPass(); }); }
-int rth_renderer_trace_photon_range(rt::Renderer* r, uint32_t first, uint32_t count, uint32_t* stored) {
-    return guarded([&] { *stored = r->tracePhotonRange(first, count); });
+int rth_renderer_trace_photon_range(rt::Renderer* r, uint32_t first, uint32_t count, int intoStaging, uint32_t* stored) {
+    return guarded([&] { *stored = r->tracePhotonRange(first, count, intoStaging != 0); });
 }
 void* rth_renderer_photon_buffer(rt::Renderer* r) { return r->photonBuffer(); }
+void* rth_renderer_photon_staging_buffer(rt::Renderer* r) { return r->photonStagingBuffer(); }
+void* rth_renderer_output_buffer(rt::Renderer* r) { return r->outputBuffer(); }
 uint32_t rth_renderer_photon_capacity(rt::Renderer* r) { return r->photonCapacity(); }
 uint32_t rth_renderer_photon_emissions(rt::Renderer* r) { return r->photonEmissions(); }
 int rth_renderer_finish_photon_pass(rt::Renderer* r, uint32_t total) {

@@ -1,9 +1,20 @@
-// Host runtime of rt::Renderer on top of the engine's C ABI (include/rt_engine.h).
+// rt::Renderer on top of the engine's C ABI (include/rt_engine.h).
 //
-// Follows the reference's src/renderer.cpp step by step - uploads, per-geometry
-// and instance acceleration builds, light table, photon buffers and constants,
-// camera set-up, reset, photon pass, sample launch, read-backs - with the OptiX
-// and CUDA calls replaced by the engine's entry points and the HIP runtime.
+// The class does what the reference's src/renderer.cpp does between a loaded rt::Scene and
+// the launches - tables for the device, acceleration structures, light list, photon map
+// constants, camera frame, the sample and photon-pass loops, read-backs - organised for this
+// engine rather than for OptiX:
+//
+//   * device memory comes from three pools (scene data, frame buffers, photon map), each one
+//     hipMalloc; the scene pool is filled on the host and uploaded with a single copy, so a
+//     scene of thousands of meshes and textures costs one allocation and one transfer
+//     instead of one of each per table;
+//   * the host-side arithmetic that ends up in device tables (light weights, environment
+//     distribution, scene bounds, camera frame, caustic radius) sits in free functions that
+//     evaluate exactly the expressions of the reference, operation by operation, because the
+//     integrator's random decisions depend on the resulting floats; each cites its lines;
+//   * a frame is rendered as bands of eight pixel rows: cut into parts that run side by side
+//     on streams of their own, and, when several GPUs share a frame, dealt out in turn.
 #include "renderer.hpp"
 
 #include "photon_grid.hpp"
@@ -12,724 +23,805 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
 #include <string>
-#include <utility>
 
 namespace rt {
 namespace {
 
-void hipCheck(hipError_t result) {
-    if (result != hipSuccess)
-        throw std::runtime_error(hipGetErrorString(result));  // renderer.cpp:30-33
+// ---- failures ------------------------------------------------------------------------------------
+
+[[noreturn]] void raise(const std::string& message) { throw std::runtime_error(message); }
+
+// The reference reports the runtime's own error string (renderer.cpp:30-33).
+void hipOk(hipError_t status) {
+    if (status != hipSuccess)
+        raise(hipGetErrorString(status));
 }
 
-void engineCheck(rt_status status, const char* operation) {
+void engineOk(rt_status status, const char* call) {
     if (status != RT_SUCCESS)
-        throw std::runtime_error(std::string(operation) + ": " + rt_last_error());  // renderer.cpp:35-39
+        raise(std::string(call) + ": " + rt_last_error());
 }
 
-// Move-only device allocation, renderer.cpp:41-93.
-class Buffer {
-public:
-    Buffer() = default;
-    explicit Buffer(std::size_t bytes) { resize(bytes); }
-    ~Buffer() { reset(); }
-    Buffer(Buffer&& other) noexcept : data_(std::exchange(other.data_, nullptr)), size_(std::exchange(other.size_, 0)) {}
-    Buffer& operator=(Buffer&& other) noexcept {
-        if (this != &other) {
-            reset();
-            data_ = std::exchange(other.data_, nullptr);
-            size_ = std::exchange(other.size_, 0);
-        }
-        return *this;
-    }
-    Buffer(const Buffer&) = delete;
-    Buffer& operator=(const Buffer&) = delete;
+// ---- device memory -------------------------------------------------------------------------------
 
-    void resize(std::size_t bytes) {
-        if (bytes == size_)
-            return;
-        reset();
-        if (bytes)
-            hipCheck(hipMalloc(&data_, bytes));
-        size_ = bytes;
+constexpr std::size_t kBlockAlignment = 256;
+
+// Hands out aligned offsets inside a pool that does not exist yet.
+class Layout {
+public:
+    std::size_t take(std::size_t bytes) {
+        const std::size_t offset = (end_ + kBlockAlignment - 1) / kBlockAlignment * kBlockAlignment;
+        end_ = offset + bytes;
+        return offset;
     }
-    void upload(const void* source, std::size_t bytes) {
-        resize(bytes);
-        if (bytes)
-            hipCheck(hipMemcpy(data_, source, bytes, hipMemcpyHostToDevice));
-    }
-    void* data() const { return data_; }
-    std::size_t size() const { return size_; }
+    std::size_t bytes() const { return end_; }
 
 private:
-    void reset() {
-        if (data_)
-            (void)hipFree(data_);
-        data_ = nullptr;
-        size_ = 0;
-    }
-    void* data_ = nullptr;
-    std::size_t size_ = 0;
+    std::size_t end_ = 0;
 };
 
-rt_float3 f3(float x, float y, float z) { return rt_float3{x, y, z}; }
+// One device allocation that tables are carved out of.
+class DevicePool {
+public:
+    DevicePool() = default;
+    DevicePool(const DevicePool&) = delete;
+    DevicePool& operator=(const DevicePool&) = delete;
+    ~DevicePool() { release(); }
 
-rt_float3 normalized(float x, float y, float z) {  // renderer.cpp:103-106
-    const float inverse = 1.0f / std::sqrt(x * x + y * y + z * z);
-    return f3(x * inverse, y * inverse, z * inverse);
+    void allocate(std::size_t bytes) {
+        release();
+        if (bytes == 0)
+            return;
+        void* memory = nullptr;
+        hipOk(hipMalloc(&memory, bytes));
+        base_ = static_cast<unsigned char*>(memory);
+        bytes_ = bytes;
+    }
+    void release() {
+        if (base_)
+            (void)hipFree(base_);
+        base_ = nullptr;
+        bytes_ = 0;
+    }
+    template <typename T>
+    T* at(std::size_t offset) const {
+        return reinterpret_cast<T*>(base_ + offset);
+    }
+    std::size_t bytes() const { return bytes_; }
+
+private:
+    unsigned char* base_ = nullptr;
+    std::size_t bytes_ = 0;
+};
+
+// Host image of a pool: blocks are appended at the offsets a Layout hands out, pointers
+// between blocks are written once the pool's address is known, then everything goes up in one copy.
+class Staging {
+public:
+    std::size_t append(const void* data, std::size_t bytes) {
+        const std::size_t offset = layout_.take(bytes);
+        image_.resize(layout_.bytes());
+        if (bytes)
+            std::memcpy(image_.data() + offset, data, bytes);
+        return offset;
+    }
+    template <typename T>
+    std::size_t reserve(std::size_t count) {
+        const std::size_t offset = layout_.take(count * sizeof(T));
+        image_.resize(layout_.bytes());
+        return offset;
+    }
+    template <typename T>
+    T* at(std::size_t offset) {
+        return reinterpret_cast<T*>(image_.data() + offset);
+    }
+    std::size_t bytes() const { return image_.size(); }
+
+private:
+    Layout layout_;
+    std::vector<unsigned char> image_;
+};
+
+// ---- float3 arithmetic in the reference's evaluation order ---------------------------------------
+
+struct F3 {
+    float x, y, z;
+};
+
+inline rt_float3 packed(F3 v) { return rt_float3{v.x, v.y, v.z}; }
+inline F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 scaled(F3 v, float k) { return {v.x * k, v.y * k, v.z * k}; }
+inline float norm(F3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+inline F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// reciprocal length first, then three products (renderer.cpp:103-106)
+inline F3 unit(float x, float y, float z) { return scaled(F3{x, y, z}, 1.0f / norm(F3{x, y, z})); }
+// Rec. 709 weights (renderer.cpp:166-168)
+inline float relativeLuminance(F3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+// column-major 4x4 times (p, 1), sums left to right (renderer.cpp:145-151)
+inline F3 toWorld(const Mat4& transform, const Vec3& p) {
+    const auto& m = transform.values;
+    return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
 }
 
-rt_gpu_texture_ref gpuTextureRef(const TextureRef& source) {  // renderer.cpp:108-119
-    if (source.texture >= 0 && source.texCoord > 1)
-        throw std::runtime_error("Only glTF TEXCOORD_0 and TEXCOORD_1 are supported");
-    rt_gpu_texture_ref ref;
-    ref.texture = source.texture;
-    ref.texCoord = source.texCoord;
-    ref.offset.x = source.offset.x;
-    ref.offset.y = source.offset.y;
-    ref.scale.x = source.scale.x;
-    ref.scale.y = source.scale.y;
-    ref.rotation = source.rotation;
-    ref.strength = source.strength;
-    return ref;
+// ---- tables derived from the scene (host arithmetic the device depends on) -----------------------
+
+// renderer.cpp:108-143: the device's material record.
+rt_gpu_material deviceMaterial(const Material& from) {
+    rt_gpu_material to;
+    std::memset(&to, 0, sizeof(to));
+    to.baseColor = rt_float4{from.baseColor.x, from.baseColor.y, from.baseColor.z, from.baseColor.w};
+    to.emissive = rt_float3{from.emissive.x, from.emissive.y, from.emissive.z};
+    to.attenuationColor = rt_float3{from.attenuationColor.x, from.attenuationColor.y, from.attenuationColor.z};
+    to.metallic = from.metallic;
+    to.roughness = from.roughness;
+    to.transmission = from.transmission;
+    to.ior = from.ior;
+    to.thickness = from.thickness;
+    to.attenuationDistance = from.attenuationDistance;
+    to.emissiveStrength = from.emissiveStrength;
+    to.dispersion = from.dispersion;
+    const std::pair<const TextureRef*, rt_gpu_texture_ref*> slots[] = {
+        {&from.baseColorTexture, &to.baseColorTexture},       {&from.metallicRoughnessTexture, &to.metallicRoughnessTexture},
+        {&from.normalTexture, &to.normalTexture},             {&from.emissiveTexture, &to.emissiveTexture},
+        {&from.transmissionTexture, &to.transmissionTexture}, {&from.thicknessTexture, &to.thicknessTexture}};
+    for (const auto& [source, target] : slots) {
+        if (source->texture >= 0 && source->texCoord > 1)
+            raise("Only glTF TEXCOORD_0 and TEXCOORD_1 are supported");  // renderer.cpp:109-110
+        target->texture = source->texture;
+        target->texCoord = source->texCoord;
+        target->offset = rt_float2{source->offset.x, source->offset.y};
+        target->scale = rt_float2{source->scale.x, source->scale.y};
+        target->rotation = source->rotation;
+        target->strength = source->strength;
+    }
+    return to;
 }
 
-rt_gpu_material gpuMaterial(const Material& source) {  // renderer.cpp:121-143
-    rt_gpu_material m;
-    std::memset(&m, 0, sizeof(m));
-    m.baseColor.x = source.baseColor.x;
-    m.baseColor.y = source.baseColor.y;
-    m.baseColor.z = source.baseColor.z;
-    m.baseColor.w = source.baseColor.w;
-    m.emissive = f3(source.emissive.x, source.emissive.y, source.emissive.z);
-    m.attenuationColor = f3(source.attenuationColor.x, source.attenuationColor.y, source.attenuationColor.z);
-    m.metallic = source.metallic;
-    m.roughness = source.roughness;
-    m.transmission = source.transmission;
-    m.ior = source.ior;
-    m.thickness = source.thickness;
-    m.attenuationDistance = source.attenuationDistance;
-    m.emissiveStrength = source.emissiveStrength;
-    m.dispersion = source.dispersion;
-    m.baseColorTexture = gpuTextureRef(source.baseColorTexture);
-    m.metallicRoughnessTexture = gpuTextureRef(source.metallicRoughnessTexture);
-    m.normalTexture = gpuTextureRef(source.normalTexture);
-    m.emissiveTexture = gpuTextureRef(source.emissiveTexture);
-    m.transmissionTexture = gpuTextureRef(source.transmissionTexture);
-    m.thicknessTexture = gpuTextureRef(source.thicknessTexture);
-    return m;
+// renderer.cpp:301-341: the latitude/longitude map as the device reads it, the running sum of
+// luminance x sin(latitude) normalised to a distribution, and the map's power as a light.
+struct EnvironmentTable {
+    std::vector<rt_float4> texels;
+    std::vector<float> distribution;
+    float power = 0.0f;
+};
+
+EnvironmentTable environmentTable(const Environment& sky) {
+    EnvironmentTable table;
+    const std::size_t count = sky.pixels.size();
+    if (count == 0)
+        return table;
+    table.texels.resize(count);
+    table.distribution.resize(count);
+    double sum = 0.0;
+    std::size_t at = 0;
+    for (std::uint32_t row = 0; row < sky.height; ++row) {
+        const float sine = std::sin(3.14159265f * (static_cast<float>(row) + 0.5f) / sky.height);
+        for (std::uint32_t column = 0; column < sky.width; ++column, ++at) {
+            const auto& texel = sky.pixels[at];
+            table.texels[at] = rt_float4{texel.x, texel.y, texel.z, texel.w};
+            sum += relativeLuminance(F3{texel.x, texel.y, texel.z}) * sine;
+            table.distribution[at] = static_cast<float>(sum);
+        }
+    }
+    if (sum <= 0.0)
+        return EnvironmentTable{};  // a black map is no light (renderer.cpp:326-327)
+    for (float& value : table.distribution)
+        value = static_cast<float>(value / sum);
+    table.power = static_cast<float>(sum * 19.7392088 / static_cast<double>(sky.width * sky.height) * sky.strength);
+    return table;
 }
 
-rt_float3 point(const Mat4& matrix, const Vec3& value) {  // renderer.cpp:145-151
-    const auto& m = matrix.values;
-    return f3(m[0] * value.x + m[4] * value.y + m[8] * value.z + m[12],
-              m[1] * value.x + m[5] * value.y + m[9] * value.z + m[13],
-              m[2] * value.x + m[6] * value.y + m[10] * value.z + m[14]);
+// renderer.cpp:436-507: emissive triangles in world space (weight = area x luminance), then the
+// punctual lights (weight = luminance x solid angle), then the environment; `total` is the sum of
+// the weights in list order.
+struct LightTable {
+    std::vector<rt_gpu_light> lights;
+    float total = 0.0f;
+};
+
+LightTable lightTable(const Scene& scene, float environmentPower) {
+    LightTable table;
+    auto blank = [] {
+        rt_gpu_light light;
+        std::memset(&light, 0, sizeof(light));
+        light.instance = light.primitive = 0xffffffffU;
+        return light;
+    };
+    for (std::size_t i = 0; i < scene.instances.size(); ++i) {
+        const Instance& instance = scene.instances[i];
+        const Geometry& mesh = scene.geometries[instance.geometry];
+        const Material& surface = scene.materials[mesh.material];
+        const F3 emission = scaled(F3{surface.emissive.x, surface.emissive.y, surface.emissive.z}, surface.emissiveStrength);
+        if (relativeLuminance(emission) <= 0.0f)
+            continue;
+        for (std::size_t t = 0; t + 2 < mesh.indices.size(); t += 3) {
+            const F3 a = toWorld(instance.transform, mesh.vertices[mesh.indices[t]].position);
+            const F3 b = toWorld(instance.transform, mesh.vertices[mesh.indices[t + 1]].position);
+            const F3 c = toWorld(instance.transform, mesh.vertices[mesh.indices[t + 2]].position);
+            const F3 areaVector = cross(b - a, c - a);
+            const float twiceArea = norm(areaVector);
+            if (twiceArea <= 1e-8f)
+                continue;  // renderer.cpp:458-459
+            rt_gpu_light light = blank();
+            light.a = packed(a);
+            light.b = packed(b);
+            light.c = packed(c);
+            light.normal = rt_float3{areaVector.x / twiceArea, areaVector.y / twiceArea, areaVector.z / twiceArea};
+            light.emission = packed(emission);
+            light.area = 0.5f * twiceArea;
+            light.weight = light.area * relativeLuminance(emission);
+            light.instance = static_cast<std::uint32_t>(i);
+            light.primitive = static_cast<std::uint32_t>(t / 3);
+            light.type = 3U;
+            table.lights.push_back(light);
+        }
+    }
+    for (const Light& source : scene.lights) {
+        const auto& m = source.transform.values;
+        const F3 emission = scaled(F3{source.color.x, source.color.y, source.color.z}, source.intensity);
+        float solidAngle = 1.0f;  // directional
+        if (source.type == 1U)
+            solidAngle = 6.2831853f * (1.0f - std::cos(source.outerCone));
+        else if (source.type == 2U)
+            solidAngle = 12.566371f;
+        rt_gpu_light light = blank();
+        light.a = rt_float3{m[12], m[13], m[14]};
+        light.b = packed(unit(-m[8], -m[9], -m[10]));  // the light looks down its -Z
+        light.emission = packed(emission);
+        light.weight = relativeLuminance(emission) * solidAngle;
+        light.range = source.range;
+        light.innerCone = source.innerCone;
+        light.outerCone = source.outerCone;
+        light.type = source.type;
+        table.lights.push_back(light);
+    }
+    if (environmentPower > 0.0f) {
+        rt_gpu_light light = blank();
+        light.weight = environmentPower;
+        light.type = 4U;
+        table.lights.push_back(light);
+    }
+    for (const rt_gpu_light& light : table.lights)
+        table.total += light.weight;
+    return table;
 }
 
-rt_float3 difference(rt_float3 a, rt_float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+// renderer.cpp:509-528: centre of the box around every transformed vertex and 0.525 of its diagonal.
+struct SceneSphere {
+    F3 centre{0.0f, 0.0f, 0.0f};
+    float radius = 0.0f;
+};
 
-rt_float3 crossProduct(rt_float3 a, rt_float3 b) {
-    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+SceneSphere sceneSphere(const Scene& scene) {
+    const float big = std::numeric_limits<float>::max();
+    F3 lo{big, big, big}, hi{-big, -big, -big};
+    for (const Instance& instance : scene.instances)
+        for (const Vertex& vertex : scene.geometries[instance.geometry].vertices) {
+            const F3 p = toWorld(instance.transform, vertex.position);
+            lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+            hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+        }
+    SceneSphere sphere;
+    sphere.centre = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
+    sphere.radius = norm(hi - lo) * 0.525f;
+    return sphere;
 }
 
-float length(rt_float3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+// renderer.cpp:672-700: image-plane frame of a camera that looks down its -Z, and the photon gather
+// radius: one pixel's footprint at the focus depth (clamped between the near plane and the scene's
+// diameter), never below half a millimetre.
+struct CameraFrame {
+    F3 eye, u, v, w, lensU, lensV;
+    float gatherRadius;
+};
 
-float luminance(rt_float3 v) { return 0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z; }  // renderer.cpp:166-168
+CameraFrame cameraFrame(const Camera& camera, std::uint32_t width, std::uint32_t height, float sceneRadius) {
+    const auto& m = camera.transform.values;
+    const F3 right = unit(m[0], m[1], m[2]);
+    const F3 up = unit(m[4], m[5], m[6]);
+    const F3 back = unit(m[8], m[9], m[10]);
+    const float aspect = camera.aspectRatio > 0.0f ? camera.aspectRatio : static_cast<float>(width) / static_cast<float>(height);
+    const float halfHeight = std::tan(camera.verticalFov * 0.5f);
+    CameraFrame frame;
+    frame.eye = {m[12], m[13], m[14]};
+    frame.u = {right.x * halfHeight * aspect, right.y * halfHeight * aspect, right.z * halfHeight * aspect};
+    frame.v = {up.x * halfHeight, up.y * halfHeight, up.z * halfHeight};
+    frame.w = {-back.x, -back.y, -back.z};
+    frame.lensU = right;
+    frame.lensV = up;
+    constexpr float radiusInPixels = 1.0f;  // renderer.cpp:173
+    const float depth = std::clamp(camera.focusDistance, camera.nearPlane, sceneRadius * 2.0f);
+    frame.gatherRadius = std::max(2.0f * radiusInPixels * depth * halfHeight / static_cast<float>(height), 0.0005f);
+    return frame;
+}
 
-constexpr float CausticRadiusPixels = 1.0f;          // renderer.cpp:173
-constexpr std::uint32_t PhotonRebuildInterval = 4U;  // renderer.cpp:177
+// Every index one table of the scene holds into another (instance -> geometry -> material ->
+// texture -> image, triangle -> vertex) is checked before anything is uploaded: the device code
+// follows them without looking, and a bad one is better an exception than a read outside a buffer.
+// (The reference relies on its loader for this.)
+void checkReferences(const Scene& scene) {
+    auto broken = [](const char* what, const std::string& name) {
+        raise(name.empty() ? std::string(what) : std::string(what) + " (" + name + ")");
+    };
+    for (const Instance& instance : scene.instances)
+        if (instance.geometry >= scene.geometries.size())
+            broken("An instance refers to a geometry the scene does not have", instance.name);
+    for (const Geometry& mesh : scene.geometries) {
+        if (mesh.material >= scene.materials.size())
+            broken("A geometry refers to a material the scene does not have", mesh.name);
+        if (mesh.indices.size() % 3 != 0)
+            broken("The index count of a geometry is not a multiple of three", mesh.name);
+        const std::size_t vertexCount = mesh.vertices.size();
+        if (std::any_of(mesh.indices.begin(), mesh.indices.end(), [&](std::uint32_t index) { return index >= vertexCount; }))
+            broken("A triangle refers to a vertex its geometry does not have", mesh.name);
+    }
+    for (const Material& material : scene.materials)
+        for (const TextureRef* slot : {&material.baseColorTexture, &material.metallicRoughnessTexture, &material.normalTexture,
+                                       &material.emissiveTexture, &material.transmissionTexture, &material.thicknessTexture})
+            if (slot->texture >= 0 && static_cast<std::size_t>(slot->texture) >= scene.textures.size())
+                broken("A material refers to a texture the scene does not have", material.name);
+    for (const Texture& texture : scene.textures)
+        if (texture.image < 0 || static_cast<std::size_t>(texture.image) >= scene.images.size())
+            broken("A texture refers to an image the scene does not have", texture.name);
+}
+
+constexpr std::uint32_t kPhotonRebuildInterval = 4U;  // renderer.cpp:177: a new photon map every fourth sample
+constexpr std::uint32_t kBandRows = 8U;               // rows per band of a frame (the engine's tile height)
 
 }  // namespace
 
 struct Renderer::Impl {
-    struct GeometryState {
-        Buffer vertices;
-        Buffer indices;
+    // ---- scene data resident on the device --------------------------------------------------------
+    struct Mesh {
+        std::size_t vertices = 0, indices = 0;  // offsets in the scene pool
+        std::uint32_t vertexCount = 0, triangleCount = 0, material = 0;
         rt_blas* blas = nullptr;
-        std::uint32_t material = 0;
     };
-    struct ImageState {
-        Buffer pixels;
-        std::uint32_t width = 0;
-        std::uint32_t height = 0;
+    DevicePool scenePool;
+    std::vector<Mesh> meshes;
+    rt_scene* tree = nullptr;
+
+    // ---- frame buffers ------------------------------------------------------------------------------
+    DevicePool framePool;
+    std::array<std::size_t, 7> aovOffset{};  // accumulation, diffuse, reflection, refraction, caustics, albedo, normal
+    std::size_t aovBytes = 0, outputOffset = 0, outputBytes = 0;
+
+    // ---- photon map -----------------------------------------------------------------------------------
+    DevicePool photonPool;
+    struct PhotonBlocks {
+        std::size_t photons = 0, sorted = 0, cellCounts = 0, cellStart = 0, counter = 0, scan = 0, bucketBits = 0;
+        std::size_t scanBytes = 0;
+    } photonAt;
+    rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
+    std::uint32_t photonWavefrontCapacity = 0;
+    float gatherRadius = 0.0f;
+    bool caustics = false;
+    bool overflowReported = false;
+    bool manualPhotonPasses = false;
+    bool photonPassPending = true;
+
+    // ---- launch state ---------------------------------------------------------------------------------
+    rt_launch_params launch;
+    std::uint32_t width = 0, height = 0, sample = 0;
+    std::uint32_t sampleFirst = 0, sampleStride = 1;
+    // what render() covers: every bandStride-th band from firstBand on (the whole frame by default), or
+    // the pixel range [rangeBegin, rangeEnd) when rangeSet
+    std::uint32_t firstBand = 0, bandStride = 1;
+    bool rangeSet = false;
+    std::uint32_t rangeBegin = 0, rangeEnd = 0;
+    struct Part {
+        rt_wavefront* wavefront = nullptr;
+        hipStream_t stream = nullptr;
     };
+    std::vector<Part> parts;
+    std::uint32_t measurementFlags = 0;
+    static constexpr std::uint32_t kDefaultParts = 3;
 
     ~Impl() {
         (void)hipDeviceSynchronize();
-        destroyTiles();
+        destroyParts();
         if (photonWavefront)
             rt_wavefront_destroy(photonWavefront);
-        if (sceneHandle)
-            rt_scene_destroy(sceneHandle);
-        for (auto& g : geometries)
-            if (g.blas)
-                rt_blas_destroy(g.blas);
+        if (tree)
+            rt_scene_destroy(tree);
+        for (Mesh& mesh : meshes)
+            if (mesh.blas)
+                rt_blas_destroy(mesh.blas);
     }
 
+    // renderer.cpp:215-254
     void initialize(const Scene& scene, std::uint32_t renderWidth, std::uint32_t renderHeight, Profile profile) {
         if (scene.instances.empty())
-            throw std::runtime_error("The scene has no geometry");  // renderer.cpp:217-218
+            raise("The scene has no geometry");  // renderer.cpp:217-218
         if (scene.cameras.empty())
-            throw std::runtime_error(
-                "The scene has no perspective camera. Blender's File > Export > glTF "
-                "leaves Cameras unchecked by default; use the Raytracer panel's "
-                "Export GLB instead");  // renderer.cpp:219-223
+            raise("The scene has no perspective camera. Blender's File > Export > glTF leaves Cameras unchecked by "
+                  "default; use the Raytracer panel's Export GLB instead");  // renderer.cpp:219-223
         if (renderWidth == 0 || renderHeight == 0)
-            throw std::runtime_error("The image has no pixels");
+            raise("The image has no pixels");
+        if (scene.materials.empty())
+            raise("The scene has no materials");
         checkReferences(scene);
         width = renderWidth;
         height = renderHeight;
         std::memset(&launch, 0, sizeof(launch));
-        launch.maxDepth = profile == Profile::Final ? 32U : 5U;  // renderer.cpp:226
-        hipCheck(hipFree(nullptr));
-
-        uploadTextures(scene);
-        uploadMaterials(scene);
-        uploadEnvironment(scene);
-        buildGeometry(scene);
-        buildInstances(scene);
-        buildLights(scene);
-        configureCaustics(scene);
-        createBindingTable();
-        const std::size_t pixels = static_cast<std::size_t>(width) * height;
-        for (auto& buffer : aov)
-            buffer.resize(pixels * sizeof(rt_float4));
-        output.resize(pixels * sizeof(rt_uchar4));
-        createTiles(DefaultTiles);
-        pixelBegin = 0;
-        pixelEnd = static_cast<std::uint32_t>(pixels);
-        causticsEnabled = profile == Profile::Final;  // renderer.cpp:251
-        configureCamera(scene.cameras.front());
-        reset();
-    }
-
-    // Every index one table of the scene holds into another (instance -> geometry ->
-    // material -> texture -> image, triangle -> vertex) is checked here: the device
-    // code follows them without looking, and a bad one is better an exception than
-    // a read outside a buffer.  (The reference relies on its loader for this.)
-    static void checkReferences(const Scene& scene) {
-        auto fail = [](const std::string& what, const std::string& name) {
-            throw std::runtime_error(what + (name.empty() ? std::string() : " (" + name + ")"));
-        };
-        for (const auto& instance : scene.instances)
-            if (instance.geometry >= scene.geometries.size())
-                fail("An instance refers to a geometry the scene does not have", instance.name);
-        for (const auto& geometry : scene.geometries) {
-            if (geometry.material >= scene.materials.size())
-                fail("A geometry refers to a material the scene does not have", geometry.name);
-            if (geometry.indices.size() % 3 != 0)
-                fail("The index count of a geometry is not a multiple of three", geometry.name);
-            for (const std::uint32_t index : geometry.indices)
-                if (index >= geometry.vertices.size())
-                    fail("A triangle refers to a vertex its geometry does not have", geometry.name);
-        }
-        for (const auto& material : scene.materials)
-            for (const TextureRef* ref : {&material.baseColorTexture, &material.metallicRoughnessTexture,
-                                          &material.normalTexture, &material.emissiveTexture,
-                                          &material.transmissionTexture, &material.thicknessTexture})
-                if (ref->texture >= 0 && static_cast<std::size_t>(ref->texture) >= scene.textures.size())
-                    fail("A material refers to a texture the scene does not have", material.name);
-        for (const auto& texture : scene.textures)
-            if (texture.image < 0 || static_cast<std::size_t>(texture.image) >= scene.images.size())
-                fail("A texture refers to an image the scene does not have", texture.name);
-    }
-
-    void uploadMaterials(const Scene& scene) {  // renderer.cpp:256-262
-        std::vector<rt_gpu_material> gpuMaterials;
-        gpuMaterials.reserve(scene.materials.size());
-        for (const auto& material : scene.materials)
-            gpuMaterials.push_back(gpuMaterial(material));
-        if (gpuMaterials.empty())
-            throw std::runtime_error("The scene has no materials");
-        materials.upload(gpuMaterials.data(), gpuMaterials.size() * sizeof(rt_gpu_material));
-    }
-
-    void uploadTextures(const Scene& scene) {  // renderer.cpp:264-299
-        images.reserve(scene.images.size());
-        for (const auto& source : scene.images) {
-            if (source.rgba.empty() || source.rgba.size() != static_cast<std::size_t>(source.width) * source.height * 4)
-                throw std::runtime_error("Unable to decode texture " + source.name +
-                                         ": this build takes decoded RGBA8 pixels only");  // renderer.cpp:275-277
-            auto& image = images.emplace_back();
-            image.width = source.width;
-            image.height = source.height;
-            image.pixels.upload(source.rgba.data(), source.rgba.size());
-        }
-        std::vector<rt_gpu_texture> records;
-        records.reserve(scene.textures.size());
-        for (const auto& source : scene.textures) {
-            const auto& image = images.at(static_cast<std::size_t>(source.image));
-            rt_gpu_texture record;
-            record.pixels = static_cast<const rt_uchar4*>(image.pixels.data());
-            record.width = image.width;
-            record.height = image.height;
-            record.wrapU = source.wrapU;
-            record.wrapV = source.wrapV;
-            records.push_back(record);
-        }
-        if (!records.empty()) {
-            textures.upload(records.data(), records.size() * sizeof(rt_gpu_texture));
-            launch.textures = static_cast<const rt_gpu_texture*>(textures.data());
-        }
-    }
-
-    void uploadEnvironment(const Scene& scene) {  // renderer.cpp:301-341
-        const auto& source = scene.environment;
-        launch.environmentRotation = source.rotation;
-        launch.environmentStrength = source.strength;
-        launch.exposure = source.exposure;
-        if (source.pixels.empty())
-            return;
-        std::vector<rt_float4> pixels;
-        std::vector<float> cdf;
-        pixels.reserve(source.pixels.size());
-        cdf.reserve(source.pixels.size());
-        double total = 0.0;
-        for (std::uint32_t y = 0; y < source.height; ++y) {
-            const float sine = std::sin(3.14159265f * (static_cast<float>(y) + 0.5f) / source.height);
-            for (std::uint32_t x = 0; x < source.width; ++x) {
-                const auto& pixel = source.pixels[y * source.width + x];
-                rt_float4 value;
-                value.x = pixel.x;
-                value.y = pixel.y;
-                value.z = pixel.z;
-                value.w = pixel.w;
-                pixels.push_back(value);
-                total += luminance(f3(pixel.x, pixel.y, pixel.z)) * sine;
-                cdf.push_back(static_cast<float>(total));
-            }
-        }
-        if (total <= 0.0)
-            return;
-        for (auto& value : cdf)
-            value = static_cast<float>(value / total);
-        environment.upload(pixels.data(), pixels.size() * sizeof(rt_float4));
-        environmentCdf.upload(cdf.data(), cdf.size() * sizeof(float));
-        launch.environment = static_cast<const rt_float4*>(environment.data());
-        launch.environmentCdf = static_cast<const float*>(environmentCdf.data());
-        launch.environmentWidth = source.width;
-        launch.environmentHeight = source.height;
-        environmentPower = static_cast<float>(total * 19.7392088 / static_cast<double>(source.width * source.height) *
-                                              source.strength);
-        launch.environmentWeight = environmentPower;
-    }
-
-    void buildGeometry(const Scene& scene) {  // renderer.cpp:343-396
-        geometries.reserve(scene.geometries.size());
-        for (const auto& geometry : scene.geometries) {
-            auto& state = geometries.emplace_back();
-            std::vector<rt_gpu_vertex> vertices;
-            vertices.reserve(geometry.vertices.size());
-            for (const auto& vertex : geometry.vertices) {
-                rt_gpu_vertex v;
-                std::memset(&v, 0, sizeof(v));
-                v.position = f3(vertex.position.x, vertex.position.y, vertex.position.z);
-                v.normal = f3(vertex.normal.x, vertex.normal.y, vertex.normal.z);
-                v.tangent.x = vertex.tangent.x;
-                v.tangent.y = vertex.tangent.y;
-                v.tangent.z = vertex.tangent.z;
-                v.tangent.w = vertex.tangent.w;
-                v.uv.x = vertex.uv.x;
-                v.uv.y = vertex.uv.y;
-                v.uv1.x = vertex.uv1.x;
-                v.uv1.y = vertex.uv1.y;
-                vertices.push_back(v);
-            }
-            state.vertices.upload(vertices.data(), vertices.size() * sizeof(rt_gpu_vertex));
-            state.indices.upload(geometry.indices.data(), geometry.indices.size() * sizeof(std::uint32_t));
-            state.material = geometry.material;
-            engineCheck(rt_blas_build(state.vertices.data(), static_cast<std::uint32_t>(geometry.vertices.size()),
-                                      sizeof(rt_gpu_vertex), static_cast<const std::uint32_t*>(state.indices.data()),
-                                      static_cast<std::uint32_t>(geometry.indices.size() / 3), nullptr, &state.blas),
-                        "rt_blas_build");
-        }
-        hipCheck(hipDeviceSynchronize());
-    }
-
-    void buildInstances(const Scene& scene) {  // renderer.cpp:398-434
-        std::vector<rt_instance_desc> instances(scene.instances.size());
-        for (std::size_t index = 0; index < scene.instances.size(); ++index) {
-            const auto& source = scene.instances[index];
-            auto& target = instances[index];
-            for (std::size_t row = 0; row < 3; ++row)
-                for (std::size_t column = 0; column < 4; ++column)
-                    target.transform[row * 4 + column] = source.transform.values[column * 4 + row];
-            target.instanceId = static_cast<std::uint32_t>(index);
-            target.geometry = source.geometry;
-            target.blas = geometries.at(source.geometry).blas;
-        }
-        engineCheck(rt_scene_build(instances.data(), static_cast<std::uint32_t>(instances.size()), nullptr, &sceneHandle),
-                    "rt_scene_build");
-        hipCheck(hipDeviceSynchronize());
-    }
-
-    void buildLights(const Scene& scene) {  // renderer.cpp:436-507
-        std::vector<rt_gpu_light> source;
-        for (std::size_t instanceIndex = 0; instanceIndex < scene.instances.size(); ++instanceIndex) {
-            const auto& instance = scene.instances[instanceIndex];
-            const auto& geometry = scene.geometries[instance.geometry];
-            const auto& material = scene.materials[geometry.material];
-            const rt_float3 emission = f3(material.emissive.x * material.emissiveStrength,
-                                          material.emissive.y * material.emissiveStrength,
-                                          material.emissive.z * material.emissiveStrength);
-            if (luminance(emission) <= 0.0f)
-                continue;
-            for (std::size_t index = 0; index < geometry.indices.size(); index += 3) {
-                const rt_float3 a = point(instance.transform, geometry.vertices[geometry.indices[index]].position);
-                const rt_float3 b = point(instance.transform, geometry.vertices[geometry.indices[index + 1]].position);
-                const rt_float3 c = point(instance.transform, geometry.vertices[geometry.indices[index + 2]].position);
-                const rt_float3 areaVector = crossProduct(difference(b, a), difference(c, a));
-                const float twiceArea = length(areaVector);
-                if (twiceArea <= 1e-8f)
-                    continue;
-                const float area = 0.5f * twiceArea;
-                rt_gpu_light light;
-                std::memset(&light, 0, sizeof(light));
-                light.a = a;
-                light.b = b;
-                light.c = c;
-                light.normal = f3(areaVector.x / twiceArea, areaVector.y / twiceArea, areaVector.z / twiceArea);
-                light.emission = emission;
-                light.area = area;
-                light.weight = area * luminance(emission);
-                light.instance = static_cast<std::uint32_t>(instanceIndex);
-                light.primitive = static_cast<std::uint32_t>(index / 3);
-                light.type = 3U;
-                source.push_back(light);
-            }
-        }
-        for (const auto& light : scene.lights) {
-            const auto& m = light.transform.values;
-            const rt_float3 emission =
-                f3(light.color.x * light.intensity, light.color.y * light.intensity, light.color.z * light.intensity);
-            const rt_float3 direction = normalized(-m[8], -m[9], -m[10]);
-            const float solidAngle = light.type == 1U ? 6.2831853f * (1.0f - std::cos(light.outerCone))
-                                     : light.type == 2U ? 12.566371f
-                                                        : 1.0f;
-            rt_gpu_light record;
-            std::memset(&record, 0, sizeof(record));
-            record.a = f3(m[12], m[13], m[14]);
-            record.b = direction;
-            record.emission = emission;
-            record.weight = luminance(emission) * solidAngle;
-            record.range = light.range;
-            record.innerCone = light.innerCone;
-            record.outerCone = light.outerCone;
-            record.instance = 0xffffffffU;
-            record.primitive = 0xffffffffU;
-            record.type = light.type;
-            source.push_back(record);
-        }
-        if (environmentPower > 0.0f) {
-            rt_gpu_light record;
-            std::memset(&record, 0, sizeof(record));
-            record.weight = environmentPower;
-            record.instance = 0xffffffffU;
-            record.primitive = 0xffffffffU;
-            record.type = 4U;
-            source.push_back(record);
-        }
-        launch.lightWeight = 0.0f;
-        for (const auto& light : source)
-            launch.lightWeight += light.weight;
-        launch.lightCount = static_cast<std::uint32_t>(source.size());
-        if (!source.empty()) {
-            lights.upload(source.data(), source.size() * sizeof(rt_gpu_light));
-            launch.lights = static_cast<const rt_gpu_light*>(lights.data());
-        }
-    }
-
-    void configureCaustics(const Scene& scene) {  // renderer.cpp:509-551
-        const float limit = std::numeric_limits<float>::max();
-        rt_float3 minimum = f3(limit, limit, limit);
-        rt_float3 maximum = f3(-limit, -limit, -limit);
-        for (const auto& instance : scene.instances)
-            for (const auto& vertex : scene.geometries[instance.geometry].vertices) {
-                const rt_float3 value = point(instance.transform, vertex.position);
-                minimum = f3(std::min(minimum.x, value.x), std::min(minimum.y, value.y), std::min(minimum.z, value.z));
-                maximum = f3(std::max(maximum.x, value.x), std::max(maximum.y, value.y), std::max(maximum.z, value.z));
-            }
-        launch.sceneCenter =
-            f3((minimum.x + maximum.x) * 0.5f, (minimum.y + maximum.y) * 0.5f, (minimum.z + maximum.z) * 0.5f);
-        launch.sceneRadius = length(difference(maximum, minimum)) * 0.525f;
-        if (launch.photonBucketCount == 0U) {
-            launch.photonBucketCount = 1U << 22U;
-            launch.photonCapacity = 1U << 23U;
-            launch.photonEmissions = 1U << 24U;
-        }
-        allocatePhotonBuffers();
-    }
-
-    void allocatePhotonBuffers() {  // renderer.cpp:537-550
-        const auto counterBytes = static_cast<std::size_t>(launch.photonBucketCount + 1U) * sizeof(std::uint32_t);
-        photons.resize(static_cast<std::size_t>(launch.photonCapacity) * sizeof(rt_photon));
-        sortedPhotons.resize(photons.size());
-        photonCellCounts.resize(counterBytes);
-        photonCellStart.resize(counterBytes);
-        photonCounter.resize(sizeof(std::uint32_t));
-        photonScan.resize(photonScanStorage(launch.photonBucketCount));
-        // until the first build every bucket is empty
-        hipCheck(hipMemset(photonCellStart.data(), 0, counterBytes));
-        // one bit per bucket, set where the bucket holds photons: the gather asks it before a range
-        const std::size_t bitBytes = std::max<std::size_t>(1, launch.photonBucketCount / 32U) * sizeof(std::uint32_t);
-        photonBucketBits.resize(bitBytes);
-        hipCheck(hipMemset(photonBucketBits.data(), 0, bitBytes));
-        bindBucketBits();
-        launch.photons = static_cast<rt_photon*>(photons.data());
-        launch.photonCount = static_cast<std::uint32_t*>(photonCounter.data());
-        launch.sortedPhotons = static_cast<const rt_photon*>(sortedPhotons.data());
-        launch.photonCellStart = static_cast<const std::uint32_t*>(photonCellStart.data());
-    }
-
-    void bindBucketBits() {
-        for (auto& t : tiles)
-            if (t.wavefront)
-                engineCheck(rt_wavefront_set_bucket_bitmap(
-                                t.wavefront, static_cast<const std::uint32_t*>(photonBucketBits.data())),
-                            "rt_wavefront_set_bucket_bitmap");
-    }
-
-    void createBindingTable() {  // renderer.cpp:633-670: one record per geometry
-        std::vector<rt_hit_group_data> records(geometries.size());
-        for (std::size_t index = 0; index < geometries.size(); ++index) {
-            records[index].vertices = static_cast<const rt_gpu_vertex*>(geometries[index].vertices.data());
-            records[index].indices = static_cast<const rt_uint3*>(geometries[index].indices.data());
-            records[index].material = geometries[index].material;
-        }
-        engineCheck(rt_scene_set_geometry(sceneHandle, records.data(), static_cast<std::uint32_t>(records.size())),
-                    "rt_scene_set_geometry");
-    }
-
-    void configureCamera(const Camera& camera) {  // renderer.cpp:672-714
-        const auto& matrix = camera.transform.values;
-        const rt_float3 right = normalized(matrix[0], matrix[1], matrix[2]);
-        const rt_float3 up = normalized(matrix[4], matrix[5], matrix[6]);
-        const rt_float3 direction = normalized(matrix[8], matrix[9], matrix[10]);
-        const rt_float3 forward = f3(-direction.x, -direction.y, -direction.z);
-        const float aspect =
-            camera.aspectRatio > 0.0f ? camera.aspectRatio : static_cast<float>(width) / static_cast<float>(height);
-        const float scale = std::tan(camera.verticalFov * 0.5f);
-        launch.eye = f3(matrix[12], matrix[13], matrix[14]);
-        launch.cameraU = f3(right.x * scale * aspect, right.y * scale * aspect, right.z * scale * aspect);
-        launch.cameraV = f3(up.x * scale, up.y * scale, up.z * scale);
-        launch.cameraW = forward;
-        launch.lensU = right;
-        launch.lensV = up;
-        launch.aperture = camera.aperture;
-        launch.focusDistance = camera.focusDistance;
-        const float depth = std::clamp(camera.focusDistance, camera.nearPlane, launch.sceneRadius * 2.0f);
-        causticRadius =
-            std::max(2.0f * CausticRadiusPixels * depth * scale / static_cast<float>(height), 0.0005f);
         launch.width = width;
         launch.height = height;
-        launch.accumulation = static_cast<rt_float4*>(aov[0].data());
-        launch.diffuse = static_cast<rt_float4*>(aov[1].data());
-        launch.reflection = static_cast<rt_float4*>(aov[2].data());
-        launch.refraction = static_cast<rt_float4*>(aov[3].data());
-        launch.caustics = static_cast<rt_float4*>(aov[4].data());
-        launch.albedoGuide = static_cast<rt_float4*>(aov[5].data());
-        launch.normalGuide = static_cast<rt_float4*>(aov[6].data());
-        launch.materials = static_cast<const rt_gpu_material*>(materials.data());
-        launch.textures = static_cast<const rt_gpu_texture*>(textures.data());
-        launch.scene = rt_scene_handle(sceneHandle);
+        hipOk(hipFree(nullptr));  // brings the runtime up (renderer.cpp:228)
+
+        uploadScene(scene);
+        buildTrees(scene);
+        const SceneSphere sphere = sceneSphere(scene);
+        launch.sceneCenter = packed(sphere.centre);
+        launch.sceneRadius = sphere.radius;
+        setPhotonSizes(1U << 24U, 1U << 23U, 1U << 22U);  // renderer.cpp:533-535
+        allocateFrame();
+        createParts(kDefaultParts);
+        applyProfile(profile);
+        applyCamera(scene.cameras.front());
+        restart();
     }
 
-    void reset() {  // renderer.cpp:716-728
-        for (auto& buffer : aov)
-            hipCheck(hipMemset(buffer.data(), 0, buffer.size()));
+    // Materials, textures and their pixels, the environment with its distribution, the light list and
+    // every mesh's vertices and indices: staged on the host at their offsets in the scene pool and
+    // uploaded with one copy (the reference: renderer.cpp:256-299, 301-341, 349-361, 436-507, one
+    // allocation and one copy per table).
+    void uploadScene(const Scene& scene) {
+        Staging staging;
+
+        std::vector<rt_gpu_material> materials;
+        materials.reserve(scene.materials.size());
+        for (const Material& material : scene.materials)
+            materials.push_back(deviceMaterial(material));
+        const std::size_t materialsAt = staging.append(materials.data(), materials.size() * sizeof(rt_gpu_material));
+
+        std::vector<std::size_t> imageAt;
+        for (const Image& image : scene.images) {
+            if (image.rgba.empty() || image.rgba.size() != static_cast<std::size_t>(image.width) * image.height * 4)
+                raise("Unable to decode texture " + image.name + ": this build takes decoded RGBA8 pixels only");  // :275-277
+            imageAt.push_back(staging.append(image.rgba.data(), image.rgba.size()));
+        }
+        const std::size_t texturesAt = staging.reserve<rt_gpu_texture>(scene.textures.size());
+
+        const EnvironmentTable sky = environmentTable(scene.environment);
+        const std::size_t skyAt = staging.append(sky.texels.data(), sky.texels.size() * sizeof(rt_float4));
+        const std::size_t skyCdfAt = staging.append(sky.distribution.data(), sky.distribution.size() * sizeof(float));
+
+        const LightTable lights = lightTable(scene, sky.power);
+        const std::size_t lightsAt = staging.append(lights.lights.data(), lights.lights.size() * sizeof(rt_gpu_light));
+
+        meshes.resize(scene.geometries.size());
+        for (std::size_t g = 0; g < scene.geometries.size(); ++g) {
+            const Geometry& source = scene.geometries[g];
+            Mesh& mesh = meshes[g];
+            mesh.vertexCount = static_cast<std::uint32_t>(source.vertices.size());
+            mesh.triangleCount = static_cast<std::uint32_t>(source.indices.size() / 3);
+            mesh.material = source.material;
+            // the 56-byte host vertex widened to the 64-byte device vertex in place (renderer.cpp:349-358)
+            mesh.vertices = staging.reserve<rt_gpu_vertex>(source.vertices.size());
+            rt_gpu_vertex* out = staging.at<rt_gpu_vertex>(mesh.vertices);
+            for (const Vertex& v : source.vertices) {
+                std::memset(out, 0, sizeof(*out));
+                out->position = rt_float3{v.position.x, v.position.y, v.position.z};
+                out->normal = rt_float3{v.normal.x, v.normal.y, v.normal.z};
+                out->tangent = rt_float4{v.tangent.x, v.tangent.y, v.tangent.z, v.tangent.w};
+                out->uv = rt_float2{v.uv.x, v.uv.y};
+                out->uv1 = rt_float2{v.uv1.x, v.uv1.y};
+                ++out;
+            }
+            mesh.indices = staging.append(source.indices.data(), source.indices.size() * sizeof(std::uint32_t));
+        }
+
+        // the pool's address is needed for the pixel pointers of the texture records
+        scenePool.allocate(staging.bytes());
+        rt_gpu_texture* records = staging.at<rt_gpu_texture>(texturesAt);
+        for (std::size_t t = 0; t < scene.textures.size(); ++t) {
+            const Texture& texture = scene.textures[t];
+            const Image& image = scene.images[static_cast<std::size_t>(texture.image)];
+            records[t].pixels = scenePool.at<const rt_uchar4>(imageAt[static_cast<std::size_t>(texture.image)]);
+            records[t].width = image.width;
+            records[t].height = image.height;
+            records[t].wrapU = texture.wrapU;
+            records[t].wrapV = texture.wrapV;
+        }
+        if (staging.bytes())
+            hipOk(hipMemcpy(scenePool.at<void>(0), staging.at<void>(0), staging.bytes(), hipMemcpyHostToDevice));
+
+        launch.materials = scenePool.at<const rt_gpu_material>(materialsAt);
+        launch.textures = scene.textures.empty() ? nullptr : scenePool.at<const rt_gpu_texture>(texturesAt);
+        launch.environmentRotation = scene.environment.rotation;
+        launch.environmentStrength = scene.environment.strength;
+        launch.exposure = scene.environment.exposure;
+        if (sky.power > 0.0f || !sky.texels.empty()) {
+            launch.environment = scenePool.at<const rt_float4>(skyAt);
+            launch.environmentCdf = scenePool.at<const float>(skyCdfAt);
+            launch.environmentWidth = scene.environment.width;
+            launch.environmentHeight = scene.environment.height;
+            launch.environmentWeight = sky.power;
+        }
+        launch.lightCount = static_cast<std::uint32_t>(lights.lights.size());
+        launch.lightWeight = lights.total;
+        launch.lights = lights.lights.empty() ? nullptr : scenePool.at<const rt_gpu_light>(lightsAt);
+    }
+
+    // One bottom-level tree per geometry, the tree over the instances, and the per-geometry records
+    // the shading kernels find vertices, indices and material through (renderer.cpp:343-434, 633-670).
+    void buildTrees(const Scene& scene) {
+        for (Mesh& mesh : meshes)
+            engineOk(rt_blas_build(scenePool.at<void>(mesh.vertices), mesh.vertexCount, sizeof(rt_gpu_vertex),
+                                   scenePool.at<const std::uint32_t>(mesh.indices), mesh.triangleCount, nullptr, &mesh.blas),
+                     "rt_blas_build");
+        std::vector<rt_instance_desc> placements(scene.instances.size());
+        for (std::size_t i = 0; i < placements.size(); ++i) {
+            const Instance& instance = scene.instances[i];
+            // rows of the column-major 4x4 (renderer.cpp:403-406)
+            for (int row = 0; row < 3; ++row)
+                for (int column = 0; column < 4; ++column)
+                    placements[i].transform[row * 4 + column] = instance.transform.values[column * 4 + row];
+            placements[i].instanceId = static_cast<std::uint32_t>(i);
+            placements[i].geometry = instance.geometry;
+            placements[i].blas = meshes[instance.geometry].blas;
+        }
+        engineOk(rt_scene_build(placements.data(), static_cast<std::uint32_t>(placements.size()), nullptr, &tree),
+                 "rt_scene_build");
+        std::vector<rt_hit_group_data> records(meshes.size());
+        for (std::size_t g = 0; g < meshes.size(); ++g) {
+            records[g].vertices = scenePool.at<const rt_gpu_vertex>(meshes[g].vertices);
+            records[g].indices = scenePool.at<const rt_uint3>(meshes[g].indices);
+            records[g].material = meshes[g].material;
+        }
+        engineOk(rt_scene_set_geometry(tree, records.data(), static_cast<std::uint32_t>(records.size())),
+                 "rt_scene_set_geometry");
+        launch.scene = rt_scene_handle(tree);
+    }
+
+    // Seven float4 buffers and the byte image (renderer.cpp:243-250) in one allocation.
+    void allocateFrame() {
+        const std::size_t pixels = static_cast<std::size_t>(width) * height;
+        Layout layout;
+        aovBytes = pixels * sizeof(rt_float4);
+        for (std::size_t& offset : aovOffset)
+            offset = layout.take(aovBytes);
+        outputBytes = pixels * sizeof(rt_uchar4);
+        outputOffset = layout.take(outputBytes);
+        framePool.allocate(layout.bytes());
+        rt_float4** targets[7] = {&launch.accumulation, &launch.diffuse,     &launch.reflection, &launch.refraction,
+                                  &launch.caustics,     &launch.albedoGuide, &launch.normalGuide};
+        for (int k = 0; k < 7; ++k)
+            *targets[k] = framePool.at<rt_float4>(aovOffset[static_cast<std::size_t>(k)]);
+    }
+
+    // Photon list, sorted copy, the two bucket tables, the counter, the sort's scratch and the bucket
+    // bits (renderer.cpp:537-550) in one allocation.
+    void setPhotonSizes(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets) {
+        launch.photonEmissions = emissions;
+        launch.photonCapacity = capacity;
+        launch.photonBucketCount = buckets;
+        Layout layout;
+        const std::size_t listBytes = static_cast<std::size_t>(capacity) * sizeof(rt_photon);
+        const std::size_t tableBytes = (static_cast<std::size_t>(buckets) + 1U) * sizeof(std::uint32_t);
+        const std::size_t bitBytes = std::max<std::size_t>(1, buckets / 32U) * sizeof(std::uint32_t);
+        photonAt.photons = layout.take(listBytes);
+        photonAt.sorted = layout.take(listBytes);
+        photonAt.cellCounts = layout.take(tableBytes);
+        photonAt.cellStart = layout.take(tableBytes);
+        photonAt.counter = layout.take(sizeof(std::uint32_t));
+        photonAt.scanBytes = photonScanStorage(buckets);
+        photonAt.scan = layout.take(photonAt.scanBytes);
+        photonAt.bucketBits = layout.take(bitBytes);
+        photonPool.allocate(layout.bytes());
+        // until the first pass every bucket is empty
+        hipOk(hipMemset(photonPool.at<void>(photonAt.cellStart), 0, tableBytes));
+        hipOk(hipMemset(photonPool.at<void>(photonAt.bucketBits), 0, bitBytes));
+        launch.photons = photonPool.at<rt_photon>(photonAt.photons);
+        launch.photonCount = photonPool.at<std::uint32_t>(photonAt.counter);
+        launch.sortedPhotons = photonPool.at<const rt_photon>(photonAt.sorted);
+        launch.photonCellStart = photonPool.at<const std::uint32_t>(photonAt.cellStart);
+        shareBucketBits();
+    }
+
+    void shareBucketBits() {
+        for (Part& part : parts)
+            if (part.wavefront)
+                engineOk(rt_wavefront_set_bucket_bitmap(part.wavefront, photonPool.at<const std::uint32_t>(photonAt.bucketBits)),
+                         "rt_wavefront_set_bucket_bitmap");
+    }
+
+    void applyProfile(Profile profile) {  // renderer.cpp:226, 251, 735-737
+        launch.maxDepth = profile == Profile::Final ? 32U : 5U;
+        caustics = profile == Profile::Final;
+    }
+
+    void applyCamera(const Camera& camera) {  // renderer.cpp:672-714
+        const CameraFrame frame = cameraFrame(camera, width, height, launch.sceneRadius);
+        launch.eye = packed(frame.eye);
+        launch.cameraU = packed(frame.u);
+        launch.cameraV = packed(frame.v);
+        launch.cameraW = packed(frame.w);
+        launch.lensU = packed(frame.lensU);
+        launch.lensV = packed(frame.lensV);
+        launch.aperture = camera.aperture;
+        launch.focusDistance = camera.focusDistance;
+        gatherRadius = frame.gatherRadius;
+    }
+
+    void restart() {  // renderer.cpp:716-728
+        for (std::size_t offset : aovOffset)
+            hipOk(hipMemset(framePool.at<void>(offset), 0, aovBytes));
         launch.photonPass = 0;
-        launch.photonRadius = causticsEnabled ? causticRadius : 0.0f;
+        launch.photonRadius = caustics ? gatherRadius : 0.0f;
         sample = 0;
     }
 
-    void beginPhotonPass() {  // renderer.cpp:742-745
-        launch.photonRadius = causticRadius;
-        hipCheck(hipMemset(photonCounter.data(), 0, photonCounter.size()));
+    // ---- photon pass (renderer.cpp:741-777), in the three steps a multi-GPU driver interleaves with
+    // its exchange
+    void beginPhotonPass() {  // :742-745
+        launch.photonRadius = gatherRadius;
+        hipOk(hipMemset(photonPool.at<void>(photonAt.counter), 0, sizeof(std::uint32_t)));
     }
 
-    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count) {  // renderer.cpp:746-769
-        // The photon pass has wavefront state of its own, sized for a whole pass (at
-        // most 2^24 paths, 328 bytes each): every batch ends with the drain of its
-        // ray launches, so few large batches beat many frame-sized ones.
+    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {  // :746-769
+        // The photon pass has wavefront state of its own, sized for a whole pass (at most 2^24 paths,
+        // 328 bytes each): every batch ends with the drain of its ray launches, so few large batches
+        // beat many frame-sized ones.
         const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
         if (!photonWavefront || photonWavefrontCapacity < wanted) {
-            hipCheck(hipDeviceSynchronize());
+            hipOk(hipDeviceSynchronize());
             if (photonWavefront)
                 rt_wavefront_destroy(photonWavefront);
             photonWavefront = nullptr;
-            engineCheck(rt_wavefront_create(wanted, &photonWavefront), "rt_wavefront_create");
+            engineOk(rt_wavefront_create(wanted, &photonWavefront), "rt_wavefront_create");
             photonWavefrontCapacity = wanted;
         }
-        engineCheck(rt_trace_photons(photonWavefront, &launch, first, count, nullptr), "rt_trace_photons");
-        hipCheck(hipDeviceSynchronize());
+        rt_launch_params pass = launch;
+        if (intoStaging)
+            pass.photons = photonPool.at<rt_photon>(photonAt.sorted);
+        engineOk(rt_trace_photons(photonWavefront, &pass, first, count, nullptr), "rt_trace_photons");
+        hipOk(hipDeviceSynchronize());
         std::uint32_t stored = 0;
-        hipCheck(hipMemcpy(&stored, photonCounter.data(), sizeof(stored), hipMemcpyDeviceToHost));
-        if (stored > launch.photonCapacity && !photonOverflowWarned) {
-            photonOverflowWarned = true;
-            std::fprintf(stderr,
-                         "warning: photon buffer full (%u of %u stored); "
-                         "the caustic will be darker than it should be\n",
+        hipOk(hipMemcpy(&stored, photonPool.at<void>(photonAt.counter), sizeof(stored), hipMemcpyDeviceToHost));
+        if (stored > launch.photonCapacity && !overflowReported) {
+            overflowReported = true;  // once, like renderer.cpp:762-768
+            std::fprintf(stderr, "warning: photon buffer full (%u of %u stored); the caustic will be darker than it should be\n",
                          stored, launch.photonCapacity);
         }
         return std::min(stored, launch.photonCapacity);
     }
 
-    void finishPhotonPass(std::uint32_t stored) {  // renderer.cpp:770-776
+    void finishPhotonPass(std::uint32_t stored) {  // :770-776
         stored = std::min(stored, launch.photonCapacity);
-        const int status = buildPhotonGrid(
-            static_cast<const Photon*>(photons.data()), stored, launch.photonRadius, launch.photonBucketCount,
-            static_cast<std::uint32_t*>(photonCellCounts.data()), static_cast<std::uint32_t*>(photonCellStart.data()),
-            photonScan.data(), photonScan.size(), static_cast<Photon*>(sortedPhotons.data()));
-        engineCheck(status, "buildPhotonGrid");
-        engineCheck(rt_photon_bucket_bitmap(static_cast<const std::uint32_t*>(photonCellStart.data()),
-                                            launch.photonBucketCount,
-                                            static_cast<std::uint32_t*>(photonBucketBits.data()), nullptr),
-                    "rt_photon_bucket_bitmap");
+        engineOk(buildPhotonGrid(photonPool.at<const Photon>(photonAt.photons), stored, launch.photonRadius,
+                                 launch.photonBucketCount, photonPool.at<std::uint32_t>(photonAt.cellCounts),
+                                 photonPool.at<std::uint32_t>(photonAt.cellStart), photonPool.at<void>(photonAt.scan),
+                                 photonAt.scanBytes, photonPool.at<Photon>(photonAt.sorted)),
+                 "buildPhotonGrid");
+        engineOk(rt_photon_bucket_bitmap(photonPool.at<const std::uint32_t>(photonAt.cellStart), launch.photonBucketCount,
+                                         photonPool.at<std::uint32_t>(photonAt.bucketBits), nullptr),
+                 "rt_photon_bucket_bitmap");
         ++launch.photonPass;
         photonPassPending = false;
     }
 
     bool photonPassDue() const {  // renderer.cpp:780
-        return launch.photonRadius > 0.0f && sample % PhotonRebuildInterval == 0U;
+        return launch.photonRadius > 0.0f && sample % kPhotonRebuildInterval == 0U;
     }
 
-    void buildCaustics() {  // renderer.cpp:741-777
-        beginPhotonPass();
-        const std::uint32_t stored = tracePhotonRange(0, launch.photonEmissions);
-        finishPhotonPass(stored);
-    }
-
-    void render(void* target) {  // renderer.cpp:779-796
+    // ---- one sample (renderer.cpp:779-796) --------------------------------------------------------------
+    void render(void* target) {
         if (photonPassDue()) {
-            if (!manualPhotonPasses)
-                buildCaustics();
-            else if (photonPassPending)
-                throw std::runtime_error("a photon pass is due: run beginPhotonPass/tracePhotonRange/finishPhotonPass");
+            if (!manualPhotonPasses) {
+                beginPhotonPass();
+                finishPhotonPass(tracePhotonRange(0, launch.photonEmissions, false));
+            } else if (photonPassPending) {
+                raise("a photon pass is due: run beginPhotonPass/tracePhotonRange/finishPhotonPass");
+            }
         }
         launch.display = nullptr;
         launch.display2 = nullptr;
         launch.display3 = nullptr;
         launch.composite = nullptr;
-        launch.output = static_cast<rt_uchar4*>(target ? target : output.data());
+        launch.output = target ? static_cast<rt_uchar4*>(target) : framePool.at<rt_uchar4>(outputOffset);
         launch.sample = sample;
-        // The pixel range is cut into one contiguous part per tile; the parts run
-        // on their own streams, so the slow rays that end one part's ray launch
-        // overlap with the other parts' work instead of idling the GPU.  The
-        // streams are ordinary (blocking) ones: work on the default stream before
-        // and after still orders against them.
-        const std::uint32_t count = pixelEnd - pixelBegin;
-        const std::uint32_t parts = static_cast<std::uint32_t>(tiles.size());
-        for (std::uint32_t k = 0; k < parts; ++k) {
-            const std::uint32_t begin = pixelBegin + static_cast<std::uint32_t>(std::uint64_t(count) * k / parts);
-            const std::uint32_t end = pixelBegin + static_cast<std::uint32_t>(std::uint64_t(count) * (k + 1) / parts);
-            engineCheck(rt_render_sample_seeded(tiles[k].wavefront, &launch, begin, end,
-                                                sampleFirst + sample * sampleStride, tiles[k].stream),
-                        "rt_render_sample");
+        const std::uint32_t seed = sampleFirst + sample * sampleStride;
+        // The parts run on their own streams, so the slow rays that end one part's ray launch overlap
+        // with the other parts' work instead of idling the GPU.  The streams are ordinary (blocking)
+        // ones: work on the default stream before and after still orders against them.
+        const std::uint32_t count = static_cast<std::uint32_t>(parts.size());
+        if (rangeSet) {
+            const std::uint64_t pixels = rangeEnd - rangeBegin;
+            for (std::uint32_t k = 0; k < count; ++k) {
+                const auto begin = rangeBegin + static_cast<std::uint32_t>(pixels * k / count);
+                const auto end = rangeBegin + static_cast<std::uint32_t>(pixels * (k + 1) / count);
+                engineOk(rt_render_sample_seeded(parts[k].wavefront, &launch, begin, end, seed, parts[k].stream),
+                         "rt_render_sample");
+            }
+        } else {
+            const std::uint32_t bands = (height + kBandRows - 1U) / kBandRows;
+            const std::uint64_t mine = firstBand < bands ? (bands - 1U - firstBand) / bandStride + 1U : 0U;
+            for (std::uint32_t k = 0; k < count; ++k) {
+                const auto from = static_cast<std::uint32_t>(mine * k / count), to = static_cast<std::uint32_t>(mine * (k + 1) / count);
+                if (to > from)
+                    engineOk(rt_render_sample_bands(parts[k].wavefront, &launch, firstBand + from * bandStride, bandStride,
+                                                    to - from, seed, parts[k].stream),
+                             "rt_render_sample_bands");
+            }
         }
         ++sample;
         photonPassPending = true;
     }
 
-    std::uint32_t width = 0;
-    std::uint32_t height = 0;
-    std::uint32_t sample = 0;
-    std::uint32_t pixelBegin = 0, pixelEnd = 0;
-    std::uint32_t sampleFirst = 0, sampleStride = 1;
-    rt_scene* sceneHandle = nullptr;
-    // Wavefront state and stream per concurrent part of the frame.
-    struct Tile {
-        rt_wavefront* wavefront = nullptr;
-        hipStream_t stream = nullptr;
-    };
-    static constexpr std::uint32_t DefaultTiles = 3;
-    std::vector<Tile> tiles;
-    rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
-    std::uint32_t photonWavefrontCapacity = 0;
-    std::uint32_t measurementFlags = 0;
-
-    void destroyTiles() {
-        for (auto& t : tiles) {
-            if (t.wavefront)
-                rt_wavefront_destroy(t.wavefront);
-            if (t.stream)
-                (void)hipStreamDestroy(t.stream);
+    // ---- the concurrent parts of a frame ------------------------------------------------------------------
+    void destroyParts() {
+        for (Part& part : parts) {
+            if (part.wavefront)
+                rt_wavefront_destroy(part.wavefront);
+            if (part.stream)
+                (void)hipStreamDestroy(part.stream);
         }
-        tiles.clear();
+        parts.clear();
     }
 
-    void createTiles(std::uint32_t count) {
-        hipCheck(hipDeviceSynchronize());
-        destroyTiles();
-        const std::size_t pixels = static_cast<std::size_t>(width) * height;
-        count = std::max<std::uint32_t>(1U, std::min<std::uint32_t>(count, 8U));
-        const std::size_t capacity = (pixels + count - 1) / count;
-        tiles.resize(count);
+    void createParts(std::uint32_t count) {
+        hipOk(hipDeviceSynchronize());
+        destroyParts();
+        count = std::clamp<std::uint32_t>(count, 1U, 8U);
+        // room for the larger of an even share of the pixels and an even share of the bands
+        const std::uint64_t pixels = static_cast<std::uint64_t>(width) * height;
+        const std::uint64_t bands = (height + kBandRows - 1U) / kBandRows;
+        const std::uint64_t capacity =
+            std::min(pixels, std::max((pixels + count - 1U) / count, (bands + count - 1U) / count * kBandRows * width));
+        parts.resize(count);
         if (count > 1)
             pickStreams();
-        for (auto& t : tiles) {
-            engineCheck(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &t.wavefront), "rt_wavefront_create");
-            engineCheck(rt_wavefront_configure(t.wavefront, measurementFlags), "rt_wavefront_configure");
-            // a single tile stays on the default stream; the parts of a split frame take half the
-            // wave slots per ray launch: two of them then trace side by side, each filling the slots
-            // the other's last rays leave idle
+        for (Part& part : parts) {
+            engineOk(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &part.wavefront), "rt_wavefront_create");
+            engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
+            // a single part stays on the default stream; the parts of a split frame take half the wave
+            // slots per ray launch: two of them then trace side by side, each filling the slots the
+            // other's last rays leave idle
             if (count > 1)
-                engineCheck(rt_wavefront_set_ray_share(t.wavefront, 1, 2), "rt_wavefront_set_ray_share");
+                engineOk(rt_wavefront_set_ray_share(part.wavefront, 1, 2), "rt_wavefront_set_ray_share");
         }
-        bindBucketBits();
+        shareBucketBits();
     }
 
-    // One stream per tile, chosen so that they run side by side.  A process has a
-    // few hardware queues (four by default) which its streams are dealt onto in
-    // turn; when other code of the process (a collective library, the caller's own
-    // streams) has taken some, two of a fresh set of streams can land on one queue
-    // and their parts of the frame then run one after the other (measured: 5.3
-    // instead of 3.7 ms per step).  So a set is probed, and a set that shares a
-    // queue is parked - which moves the next set one place on - until one is clean
-    // or a handful of sets has been tried; the last set is kept in that case.
+    // One stream per part, chosen so that they run side by side.  A process has a few hardware queues
+    // (four by default) which its streams are dealt onto in turn; when other code of the process (a
+    // collective library, the caller's own streams) has taken some, two of a fresh set of streams can
+    // land on one queue and their parts of the frame then run one after the other (measured: 5.3
+    // instead of 3.7 ms per step).  So a set is probed, and a set that shares a queue is parked - which
+    // moves the next set one place on - until one is clean or a handful of sets has been tried; the
+    // last set is kept in that case.
     void pickStreams() {
         std::vector<hipStream_t> parked;
         for (int attempt = 0;; ++attempt) {
             std::vector<void*> set;
-            for (auto& t : tiles) {
-                hipCheck(hipStreamCreate(&t.stream));
-                set.push_back(t.stream);
+            for (Part& part : parts) {
+                hipOk(hipStreamCreate(&part.stream));
+                set.push_back(part.stream);
             }
             int concurrent = 0;
-            engineCheck(rt_streams_run_concurrently(set.data(), static_cast<std::uint32_t>(set.size()), &concurrent),
-                        "rt_streams_run_concurrently");
+            engineOk(rt_streams_run_concurrently(set.data(), static_cast<std::uint32_t>(set.size()), &concurrent),
+                     "rt_streams_run_concurrently");
             if (concurrent || attempt == 5)
                 break;
             // keep one stream of the failed set alive so that the next set starts one queue further
-            parked.push_back(tiles[0].stream);
-            for (std::size_t k = 1; k < tiles.size(); ++k)
-                (void)hipStreamDestroy(tiles[k].stream);
-            for (auto& t : tiles)
-                t.stream = nullptr;
+            parked.push_back(parts[0].stream);
+            for (std::size_t k = 1; k < parts.size(); ++k)
+                (void)hipStreamDestroy(parts[k].stream);
+            for (Part& part : parts)
+                part.stream = nullptr;
         }
-        for (hipStream_t s : parked)
-            (void)hipStreamDestroy(s);
+        for (hipStream_t stream : parked)
+            (void)hipStreamDestroy(stream);
     }
-
-    std::vector<GeometryState> geometries;
-    std::vector<ImageState> images;
-    Buffer materials, textures, lights, environment, environmentCdf;
-    Buffer aov[7];  // accumulation, diffuse, reflection, refraction, caustics, albedo guide, normal guide
-    Buffer output;
-    Buffer photons, sortedPhotons, photonCellCounts, photonCellStart, photonCounter, photonScan, photonBucketBits;
-    rt_launch_params launch;
-    float environmentPower = 0.0f;
-    float causticRadius = 0.0f;
-    bool causticsEnabled = false;
-    bool photonOverflowWarned = false;
-    bool manualPhotonPasses = false;
-    bool photonPassPending = true;
 };
 
 Renderer::Renderer(const Scene& scene, std::uint32_t width, std::uint32_t height, Profile profile)
@@ -741,125 +833,131 @@ Renderer::~Renderer() = default;
 
 void Renderer::render(void* output) { impl_->render(output); }
 
-void Renderer::denoise() {
-    throw std::runtime_error("denoise: the OptiX denoiser has no counterpart in this engine");
-}
+void Renderer::denoise() { raise("denoise: the OptiX denoiser has no counterpart in this engine"); }
 
 void Renderer::setCamera(const Camera& camera) {  // renderer.cpp:730-733
-    impl_->configureCamera(camera);
-    impl_->reset();
+    impl_->applyCamera(camera);
+    impl_->restart();
 }
 
 void Renderer::setProfile(Profile profile) {  // renderer.cpp:735-739
-    impl_->launch.maxDepth = profile == Profile::Final ? 32U : 5U;
-    impl_->causticsEnabled = profile == Profile::Final;
-    impl_->reset();
+    impl_->applyProfile(profile);
+    impl_->restart();
 }
 
-void Renderer::copyOutput(void* output) const {  // renderer.cpp:888-891
-    hipCheck(hipMemcpy(output, impl_->output.data(), impl_->output.size(), hipMemcpyDeviceToDevice));
+void Renderer::copyOutput(void* output) const {  // renderer.cpp:888-891: device to device
+    hipOk(hipMemcpy(output, impl_->framePool.at<void>(impl_->outputOffset), impl_->outputBytes, hipMemcpyDeviceToDevice));
 }
 
 std::vector<std::uint8_t> Renderer::pixels() const {  // renderer.cpp:881-886
-    std::vector<std::uint8_t> result(impl_->output.size());
-    hipCheck(hipMemcpy(result.data(), impl_->output.data(), impl_->output.size(), hipMemcpyDeviceToHost));
-    return result;
+    std::vector<std::uint8_t> image(impl_->outputBytes);
+    hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->outputOffset), image.size(), hipMemcpyDeviceToHost));
+    return image;
 }
 
 std::vector<float> Renderer::linearPixels() const {  // renderer.cpp:893-899
-    const Buffer& source = impl_->aov[0];
-    std::vector<float> result(source.size() / sizeof(float));
-    hipCheck(hipMemcpy(result.data(), source.data(), source.size(), hipMemcpyDeviceToHost));
-    return result;
+    std::vector<float> image(impl_->aovBytes / sizeof(float));
+    hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->aovOffset[0]), impl_->aovBytes, hipMemcpyDeviceToHost));
+    return image;
 }
 
 std::uint32_t Renderer::samples() const { return impl_->sample; }
 
 void Renderer::setPhotonBudget(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets) {
     if (emissions == 0 || capacity == 0 || buckets == 0 || (buckets & (buckets - 1U)) != 0)
-        throw std::runtime_error("photon budget: counts must be positive and the bucket count a power of two");
-    hipCheck(hipDeviceSynchronize());
-    impl_->launch.photonEmissions = emissions;
-    impl_->launch.photonCapacity = capacity;
-    impl_->launch.photonBucketCount = buckets;
-    impl_->allocatePhotonBuffers();
-    impl_->reset();
+        raise("photon budget: counts must be positive and the bucket count a power of two");
+    hipOk(hipDeviceSynchronize());
+    impl_->setPhotonSizes(emissions, capacity, buckets);
+    impl_->restart();
 }
 
 void Renderer::setSampleSequence(std::uint32_t first, std::uint32_t stride) {
     impl_->sampleFirst = first;
     impl_->sampleStride = stride;
-    impl_->reset();
+    impl_->restart();
 }
 
 void Renderer::setPixelRange(std::uint32_t begin, std::uint32_t end) {
     if (end < begin || end > impl_->width * impl_->height)
-        throw std::runtime_error("pixel range outside the image");
-    impl_->pixelBegin = begin;
-    impl_->pixelEnd = end;
+        raise("pixel range outside the image");
+    impl_->rangeSet = true;
+    impl_->rangeBegin = begin;
+    impl_->rangeEnd = end;
+}
+
+void Renderer::setRowInterleave(std::uint32_t first, std::uint32_t stride) {
+    if (stride == 0 || first >= stride)
+        raise("row interleave: the stride must be positive and the first band below it");
+    impl_->rangeSet = false;
+    impl_->firstBand = first;
+    impl_->bandStride = stride;
 }
 
 void Renderer::setManualPhotonPasses(bool manual) { impl_->manualPhotonPasses = manual; }
 bool Renderer::photonPassDue() const { return impl_->photonPassDue(); }
 void Renderer::beginPhotonPass() { impl_->beginPhotonPass(); }
-std::uint32_t Renderer::tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount) {
-    return impl_->tracePhotonRange(firstEmission, emissionCount);
+std::uint32_t Renderer::tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging) {
+    return impl_->tracePhotonRange(firstEmission, emissionCount, intoStaging);
 }
-void* Renderer::photonBuffer() const { return impl_->photons.data(); }
+void* Renderer::photonBuffer() const { return impl_->photonPool.at<void>(impl_->photonAt.photons); }
+void* Renderer::photonStagingBuffer() const { return impl_->photonPool.at<void>(impl_->photonAt.sorted); }
 std::uint32_t Renderer::photonCapacity() const { return impl_->launch.photonCapacity; }
 std::uint32_t Renderer::photonEmissions() const { return impl_->launch.photonEmissions; }
 void Renderer::finishPhotonPass(std::uint32_t totalPhotons) { impl_->finishPhotonPass(totalPhotons); }
+
 void* Renderer::accumulationBuffer(int index) const {
     if (index < 0 || index > 6)
-        throw std::runtime_error("accumulation buffer index");
-    return impl_->aov[index].data();
+        raise("accumulation buffer index");
+    return impl_->framePool.at<void>(impl_->aovOffset[static_cast<std::size_t>(index)]);
 }
+
+void* Renderer::outputBuffer() const { return impl_->framePool.at<void>(impl_->outputOffset); }
+
 void Renderer::statistics(std::uint64_t out[8]) {
-    for (int k = 0; k < 8; ++k)
-        out[k] = 0;
-    for (auto& t : impl_->tiles) {
+    std::fill(out, out + 8, std::uint64_t{0});
+    auto add = [&](rt_wavefront* state, hipStream_t stream) {
         std::uint64_t part[8] = {};
-        engineCheck(rt_wavefront_stats(t.wavefront, part, 1, t.stream), "rt_wavefront_stats");
+        engineOk(rt_wavefront_stats(state, part, 1, stream), "rt_wavefront_stats");
         for (int k = 0; k < 8; ++k)
             out[k] += part[k];
-    }
-    if (impl_->photonWavefront) {
-        std::uint64_t part[8] = {};
-        engineCheck(rt_wavefront_stats(impl_->photonWavefront, part, 1, nullptr), "rt_wavefront_stats");
-        for (int k = 0; k < 8; ++k)
-            out[k] += part[k];
-    }
+    };
+    for (auto& part : impl_->parts)
+        add(part.wavefront, part.stream);
+    if (impl_->photonWavefront)
+        add(impl_->photonWavefront, nullptr);
 }
+
 void Renderer::setMeasurement(bool timeStages, bool countTraversal, bool gatherPerLane) {
-    impl_->measurementFlags = (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) |
-                              (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U) |
+    impl_->measurementFlags = (timeStages ? RT_WAVEFRONT_TIME_STAGES : 0U) | (countTraversal ? RT_WAVEFRONT_COUNT_TRAVERSAL : 0U) |
                               (gatherPerLane ? RT_WAVEFRONT_GATHER_PER_LANE : 0U);
-    for (auto& t : impl_->tiles)
-        engineCheck(rt_wavefront_configure(t.wavefront, impl_->measurementFlags), "rt_wavefront_configure");
+    for (auto& part : impl_->parts)
+        engineOk(rt_wavefront_configure(part.wavefront, impl_->measurementFlags), "rt_wavefront_configure");
 }
+
 void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
-    for (int k = 0; k < 5; ++k) {
-        milliseconds[k] = 0.0f;
-        launches[k] = 0;
-    }
-    for (auto& t : impl_->tiles) {
+    std::fill(milliseconds, milliseconds + 5, 0.0f);
+    std::fill(launches, launches + 5, 0U);
+    for (auto& part : impl_->parts) {
         float ms[5] = {};
         std::uint32_t n[5] = {};
-        engineCheck(rt_wavefront_timings(t.wavefront, ms, n, t.stream), "rt_wavefront_timings");
+        engineOk(rt_wavefront_timings(part.wavefront, ms, n, part.stream), "rt_wavefront_timings");
         for (int k = 0; k < 5; ++k) {
             milliseconds[k] += ms[k];
             launches[k] += n[k];
         }
     }
 }
-void Renderer::setConcurrentTiles(std::uint32_t count) { impl_->createTiles(count); }
+
+void Renderer::setConcurrentTiles(std::uint32_t count) { impl_->createParts(count); }
+
 void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
-    for (auto& t : impl_->tiles)
-        engineCheck(rt_wavefront_set_ray_share(t.wavefront, numerator, denominator), "rt_wavefront_set_ray_share");
+    for (auto& part : impl_->parts)
+        engineOk(rt_wavefront_set_ray_share(part.wavefront, numerator, denominator), "rt_wavefront_set_ray_share");
 }
-std::uint32_t Renderer::concurrentTiles() const { return static_cast<std::uint32_t>(impl_->tiles.size()); }
-void Renderer::synchronize() const { hipCheck(hipDeviceSynchronize()); }
+
+std::uint32_t Renderer::concurrentTiles() const { return static_cast<std::uint32_t>(impl_->parts.size()); }
+void Renderer::synchronize() const { hipOk(hipDeviceSynchronize()); }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }
-float Renderer::causticRadius() const { return impl_->causticRadius; }
+float Renderer::causticRadius() const { return impl_->gatherRadius; }
 
 }  // namespace rt

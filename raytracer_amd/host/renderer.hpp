@@ -49,6 +49,11 @@ public:
     void setSampleSequence(std::uint32_t first, std::uint32_t stride);
     // Restricts render() to the pixels [begin, end) in row-major order.
     void setPixelRange(std::uint32_t begin, std::uint32_t end);
+    // Restricts render() to every stride-th band of eight pixel rows, starting with band `first`
+    // (rows 8 * first ..): the share of GPU `first` of `stride` GPUs that take the bands of one
+    // frame in turn, which spreads rows that are dear to trace over all of them.  Replaces a pixel
+    // range; (0, 1), the default, is the whole frame.
+    void setRowInterleave(std::uint32_t first, std::uint32_t stride);
     // render() cuts its pixel range into `count` parts (1..8, default 3) that run
     // concurrently on streams of their own; the image does not depend on it.
     // With more than one part the stage timings of the parts overlap in time.
@@ -64,12 +69,18 @@ public:
     void setManualPhotonPasses(bool manual);
     bool photonPassDue() const;
     void beginPhotonPass();
-    std::uint32_t tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount);  // returns stored count
+    // Returns the photons stored so far in this pass.  With intoStaging they are written to
+    // photonStagingBuffer() instead of photonBuffer(): the memory of the sorted photon list, which
+    // holds nothing between beginPhotonPass() and finishPhotonPass(), so that a driver can receive
+    // every GPU's photons, its own included, straight at their final place in photonBuffer().
+    std::uint32_t tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging = false);
     void* photonBuffer() const;           // device, photonCapacity() * 36 bytes
+    void* photonStagingBuffer() const;    // device, photonCapacity() * 36 bytes
     std::uint32_t photonCapacity() const;
     std::uint32_t photonEmissions() const;
     void finishPhotonPass(std::uint32_t totalPhotons);
     void* accumulationBuffer(int index) const;  // device float4 buffers: 0 accumulation .. 6 normal guide
+    void* outputBuffer() const;                 // device RGBA8 image render() writes when given no target
     // Counters since the last call: [0] extend rays, [1] shadow rays, [2] gather
     // queries, [3] photons read by gathers, [4] nodes visited, [5] triangles
     // tested, [6] instances entered (the last three only while traversal counting

@@ -112,14 +112,17 @@ _SIG = {
     "rth_renderer_set_photon_budget": (C.c_int, [_vp, _u32, _u32, _u32]),
     "rth_renderer_set_sample_sequence": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_pixel_range": (C.c_int, [_vp, _u32, _u32]),
+    "rth_renderer_set_row_interleave": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_concurrent_tiles": (C.c_int, [_vp, _u32]),
     "rth_renderer_concurrent_tiles": (_u32, [_vp]),
     "rth_renderer_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
     "rth_renderer_begin_photon_pass": (C.c_int, [_vp]),
-    "rth_renderer_trace_photon_range": (C.c_int, [_vp, _u32, _u32, C.POINTER(_u32)]),
+    "rth_renderer_trace_photon_range": (C.c_int, [_vp, _u32, _u32, C.c_int, C.POINTER(_u32)]),
     "rth_renderer_photon_buffer": (_vp, [_vp]),
+    "rth_renderer_photon_staging_buffer": (_vp, [_vp]),
+    "rth_renderer_output_buffer": (_vp, [_vp]),
     "rth_renderer_photon_capacity": (_u32, [_vp]),
     "rth_renderer_photon_emissions": (_u32, [_vp]),
     "rth_renderer_finish_photon_pass": (C.c_int, [_vp, _u32]),
@@ -154,6 +157,13 @@ def _check(status):
         raise engine.EngineError(load().rth_last_error().decode())
 
 
+def _added(index):
+    """rth_scene_add_* return the index of the new entry, or -1 when the entry could not be stored."""
+    if index < 0:
+        raise engine.EngineError(load().rth_last_error().decode())
+    return index
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -185,28 +195,28 @@ class HostScene:
         lib = load()
         self.handle = C.c_void_p(lib.rth_scene_create())
         for m in scene["materials"]:
-            lib.rth_scene_add_material(self.handle, C.byref(gpu_material(m)))
+            _added(lib.rth_scene_add_material(self.handle, C.byref(gpu_material(m))))
         for g in scene["geometries"]:
             v = np.ascontiguousarray(g["vertices"], dtype=np.float32)
             i = np.ascontiguousarray(g["indices"], dtype=np.uint32)
-            lib.rth_scene_add_geometry(self.handle, _p(v), v.shape[0], _p(i), i.shape[0], g["material"])
+            _added(lib.rth_scene_add_geometry(self.handle, _p(v), v.shape[0], _p(i), i.shape[0], g["material"]))
         for gi, m in scene["instances"]:
             mm = np.ascontiguousarray(m, dtype=np.float32)
-            lib.rth_scene_add_instance(self.handle, gi, _p(mm))
+            _added(lib.rth_scene_add_instance(self.handle, gi, _p(mm)))
         for c in scene["cameras"]:
             mm = np.ascontiguousarray(c["transform"], dtype=np.float32)
-            lib.rth_scene_add_camera(self.handle, _p(mm), c["verticalFov"], c["aspectRatio"], c["nearPlane"],
-                                     c["aperture"], c["focusDistance"])
+            _added(lib.rth_scene_add_camera(self.handle, _p(mm), c["verticalFov"], c["aspectRatio"], c["nearPlane"],
+                                            c["aperture"], c["focusDistance"]))
         for l in scene["lights"]:
             mm = np.ascontiguousarray(l["transform"], dtype=np.float32)
             col = np.ascontiguousarray(l["color"], dtype=np.float32)
-            lib.rth_scene_add_light(self.handle, _p(mm), _p(col), l["intensity"], l["range"], l["innerCone"],
-                                    l["outerCone"], l["type"])
+            _added(lib.rth_scene_add_light(self.handle, _p(mm), _p(col), l["intensity"], l["range"], l["innerCone"],
+                                           l["outerCone"], l["type"]))
         for img in scene.get("images", []):
             px = np.ascontiguousarray(img, dtype=np.uint8)
-            lib.rth_scene_add_image(self.handle, _p(px), px.shape[1], px.shape[0])
+            _added(lib.rth_scene_add_image(self.handle, _p(px), px.shape[1], px.shape[0]))
         for t in scene.get("textures", []):
-            lib.rth_scene_add_texture(self.handle, t["image"], t.get("wrapU", 10497), t.get("wrapV", 10497))
+            _added(lib.rth_scene_add_texture(self.handle, t["image"], t.get("wrapU", 10497), t.get("wrapV", 10497)))
         env = scene.get("environment")
         if env is not None:
             px = np.ascontiguousarray(env["pixels"], dtype=np.float32)
@@ -401,6 +411,10 @@ class Renderer:
     def set_pixel_range(self, begin, end):
         _check(load().rth_renderer_set_pixel_range(self.handle, begin, end))
 
+    def set_row_interleave(self, first, stride):
+        """render() covers every stride-th band of eight pixel rows from band `first` on (replaces a pixel range)."""
+        _check(load().rth_renderer_set_row_interleave(self.handle, first, stride))
+
     def set_concurrent_tiles(self, count):
         _check(load().rth_renderer_set_concurrent_tiles(self.handle, count))
 
@@ -420,13 +434,20 @@ class Renderer:
     def begin_photon_pass(self):
         _check(load().rth_renderer_begin_photon_pass(self.handle))
 
-    def trace_photon_range(self, first, count):
+    def trace_photon_range(self, first, count, staging=False):
+        """Photons stored so far in this pass; with staging they go to photon_staging_buffer()."""
         stored = C.c_uint32(0)
-        _check(load().rth_renderer_trace_photon_range(self.handle, first, count, C.byref(stored)))
+        _check(load().rth_renderer_trace_photon_range(self.handle, first, count, int(staging), C.byref(stored)))
         return stored.value
 
     def photon_buffer(self):
         return int(load().rth_renderer_photon_buffer(self.handle) or 0)
+
+    def photon_staging_buffer(self):
+        return int(load().rth_renderer_photon_staging_buffer(self.handle) or 0)
+
+    def output_buffer(self):
+        return int(load().rth_renderer_output_buffer(self.handle) or 0)
 
     def photon_capacity(self):
         return int(load().rth_renderer_photon_capacity(self.handle))
@@ -481,13 +502,29 @@ class Renderer:
             pass
 
 
-def device_to_host(ptr, nbytes):
-    """Copies nbytes from a raw device address into a numpy byte array (hipMemcpy through torch's runtime)."""
+class _DeviceMemory:
+    """A raw device address range as an object torch.as_tensor() accepts (the CUDA array interface,
+    which the ROCm build of torch reads the same way)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def device_view(ptr, nbytes, dtype=None):
+    """A torch tensor over nbytes of device memory at `ptr` on the current device, without a copy: the
+    renderer's photon list and accumulation buffers as tensors that torch.distributed can send from and
+    receive into.  The memory stays the renderer's; the view must not outlive it."""
     import torch
-    hip = C.CDLL("libamdhip64.so")
-    out = np.empty(nbytes, dtype=np.uint8)
+    if nbytes == 0:
+        flat = torch.empty(0, dtype=torch.uint8, device="cuda")
+    else:
+        flat = torch.as_tensor(_DeviceMemory(ptr, nbytes), device="cuda")
+    return flat if dtype is None else flat.view(dtype)
+
+
+def device_to_host(ptr, nbytes):
+    """Copies nbytes from a raw device address into a numpy byte array."""
+    import torch
     torch.cuda.synchronize()
-    status = hip.hipMemcpy(_p(out), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))  # hipMemcpyDeviceToHost
-    if status != 0:
-        raise engine.EngineError(f"hipMemcpy failed with {status}")
-    return out
+    return device_view(ptr, nbytes).cpu().numpy()

@@ -1,5 +1,6 @@
-"""CPU tests (gloo, world_size 2 and 3) of the multi-GPU exchange logic: photon lists concatenated in
-rank order, row tiles gathered into the full image, shard ranges that tile the index space."""
+"""CPU tests (gloo, world_size 2 and 3) of the multi-GPU exchange logic: photon lists placed in rank
+order at their final offsets, the bands of a frame dealt out in turn and gathered into the full image,
+shard ranges that tile the index space."""
 import os
 import socket
 
@@ -42,14 +43,22 @@ def _worker(rank, world, port, result_dir):
         b0, e0 = D.shard_range(1000, 0, world)
         expect = allp[keep & ~((np.arange(1000) >= b0) & (np.arange(1000) < e0))]
         assert np.array_equal(merged2.numpy(), expect)
-        # row tiles -> full image
-        h, w = 37, 5
-        image = torch.arange(h * w * 4, dtype=torch.float32).reshape(h, w, 4)
-        r0, r1 = D.shard_range(h, rank, world)
-        full = D.gather_rows(image[r0:r1].clone(), h)
-        assert torch.equal(full, image)
-        pb, pe = D.row_range(h, w, rank, world)
-        assert (pb, pe) == (r0 * w, r1 * w)
+        # the same exchange into a caller-owned list (what the renderer's photon buffer is), own rows included
+        counts = D.gather_counts(local.shape[0], device="cpu")
+        assert counts == [int(keep[slice(*D.shard_range(1000, r, world))].sum()) for r in range(world)]
+        dest = torch.full((400, 9), -1.0)
+        kept, sent, received = D.exchange_photons_into(dest, local, counts)
+        assert kept == total and np.array_equal(dest[:kept].numpy(), allp[keep]) and (dest[kept:] == -1.0).all()
+        assert sent == local.shape[0] * 36 * (world - 1) and received == (total - local.shape[0]) * 36
+        # bands of eight rows dealt out in turn -> full image (a height that leaves a short last band,
+        # and fewer bands than ranks for the last rank)
+        for h, w in ((37, 5), (8 * world - 3, 16), (64, 8)):
+            bands = D.band_count(h)
+            image = torch.arange(bands * 8 * w * 4, dtype=torch.float32).reshape(bands, 8 * w * 4)
+            mine = image[rank::world].clone()
+            assert mine.shape[0] == len(D.owned_bands(h, rank, world))
+            full = D.gather_bands(mine, h)
+            assert torch.equal(full, image)
         open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -59,6 +68,17 @@ def _worker(rank, world, port, result_dir):
 def test_exchange_over_gloo(world, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_bands_and_photon_slots():
+    for height in (1, 8, 9, 1080, 2160, 37):
+        for world in (1, 2, 3, 8):
+            owned = [list(D.owned_bands(height, r, world)) for r in range(world)]
+            assert sorted(b for o in owned for b in o) == list(range(D.band_count(height)))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+    assert D.photon_slots([3, 0, 5], 100) == [(0, 3), (3, 0), (3, 5)]
+    assert D.photon_slots([3, 4, 5], 5) == [(0, 3), (3, 2), (7, 0)]
+    assert D.photon_slots([7, 1], 5) == [(0, 5), (7, 0)]
 
 
 def test_shard_ranges_tile_the_space():

@@ -1,5 +1,7 @@
-"""GPU test of the sharded renderer: two processes on the one card (gloo carries the collectives,
-staged through host memory) must reproduce the single-process image and photon map bit for bit."""
+"""GPU tests of the sharded renderer: two processes on the one card (gloo carries the collectives,
+staged through host memory) and one process over RCCL (backend "nccl", world size 1: the code path
+that sends from and receives into the renderer's own device buffers) must reproduce the
+single-process image and photon map bit for bit."""
 import os
 import socket
 
@@ -14,7 +16,7 @@ W, H, SAMPLES = 96, 54, 5
 BUDGET = (1 << 17, 1 << 16, 1 << 14)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     import torch
     import torch.distributed as dist
     from raytracer_amd import distributed as D
@@ -22,33 +24,58 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dr = D.DistributedRenderer(workloads.caustic_lab(), W, H, profile=R.FINAL, photon_budget=BUDGET)
         for _ in range(SAMPLES):
             dr.render()
         image = dr.linear_pixels()
         np.save(os.path.join(out_dir, f"image{rank}.npy"), image)
+        # two photon passes (before samples 0 and 4), each with its exchange record
+        assert len(dr.exchanges) == 2 and all(e["kept"] == e["photons"] > 1000 for e in dr.exchanges)
+        if world == 1:
+            assert all(e["bytes_sent"] == 0 and e["bytes_received"] == 0 for e in dr.exchanges)
+        else:
+            assert all(e["bytes_received"] > 0 for e in dr.exchanges)
+        layers = dr.gather_buffer(4)  # the caustic layer, gathered like the image
+        np.save(os.path.join(out_dir, f"caustics{rank}.npy"), layers.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one(engine, tmp_path):
-    import torch.multiprocessing as mp
-    from raytracer_amd import renderer as R
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.get_context("spawn")
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    return port
+
+
+def _single(R):
     single = R.Renderer(workloads.caustic_lab(), W, H, R.FINAL)
     single.set_photon_budget(*BUDGET)
     for _ in range(SAMPLES):
         single.render()
-    ref = single.linear_pixels()
-    for rank in range(2):
+    single.synchronize()
+    caustics = R.device_to_host(single.accumulation_buffer(4), W * H * 16).view(np.float32).reshape(H, W, 4)
+    return single.linear_pixels(), caustics
+
+
+@pytest.mark.parametrize("world, backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
+def test_ranks_equal_one_gpu(engine, tmp_path, world, backend):
+    """54 rows are six full bands and one of six rows: with two and three ranks the bands are dealt out
+    in turn, a rank ends with the short band, and every rank traces its share of the emissions."""
+    import torch.multiprocessing as mp
+    from raytracer_amd import renderer as R
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
+    ref, caustics = _single(R)
+    for rank in range(world):
         image = np.load(os.path.join(tmp_path, f"image{rank}.npy"))
         assert image.shape == ref.shape
         assert np.array_equal(image.view(np.uint32), ref.view(np.uint32)), rank
-    assert ref[..., :3].sum() > 0
+        layer = np.load(os.path.join(tmp_path, f"caustics{rank}.npy"))
+        assert np.array_equal(layer.view(np.uint32), caustics.view(np.uint32)), rank
+    assert ref[..., :3].sum() > 0 and caustics[..., :3].sum() > 0

@@ -296,6 +296,72 @@ def test_pixel_ranges_compose_to_the_full_frame(R):
     assert np.array_equal(a, full.linear_pixels().reshape(-1, 4)[: w * h // 3])
 
 
+def test_interleaved_bands_compose_to_the_full_frame(R):
+    """The bands of eight rows dealt out to 1, 2, 3 and 8 takers, each rendering its share (as the ranks of
+    a multi-GPU job do), give the full frame bit for bit: heights with a short last band, fewer bands
+    than takers, a width that is no multiple of 8 (row order inside the bands), 1 and 3 concurrent parts."""
+    scene = workloads.cornell_box(light="panel")
+    for w, h in ((64, 72), (96, 54), (50, 37), (64, 12)):
+        full = R.Renderer(scene, w, h)
+        for _ in range(2):
+            full.render()
+        want = full.linear_pixels().reshape(-1, 4)
+        want_bytes = full.pixels().reshape(-1, 4)
+        rays = full.statistics()["extend_rays"]
+        for takers, tiles in ((2, 3), (3, 1), (8, 2)):
+            got = np.zeros_like(want)
+            got_bytes = np.zeros_like(want_bytes)
+            total = 0
+            for first in range(takers):
+                part = R.Renderer(scene, w, h)
+                part.set_concurrent_tiles(tiles)
+                part.set_row_interleave(first, takers)
+                for _ in range(2):
+                    part.render()
+                rows = np.zeros(h, dtype=bool)
+                for band in range(first, (h + 7) // 8, takers):
+                    rows[band * 8:band * 8 + 8] = True
+                mask = np.repeat(rows, w)
+                image = part.linear_pixels().reshape(-1, 4)
+                assert not image[~mask].any(), "a taker wrote outside its bands"
+                got[mask] = image[mask]
+                got_bytes[mask] = part.pixels().reshape(-1, 4)[mask]
+                total += part.statistics()["extend_rays"]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, takers)
+            assert np.array_equal(got_bytes, want_bytes) and total == rays
+    r = R.Renderer(scene, 32, 32)
+    from raytracer_amd import engine
+    for bad in ((0, 0), (2, 2), (5, 3)):
+        with pytest.raises(engine.EngineError):
+            r.set_row_interleave(*bad)
+
+
+def test_render_into_and_copy_to_caller_owned_device_buffers(R):
+    """render(output) writes the byte image into a caller-owned device buffer (the interactive loop of the
+    reference hands its mapped display buffer over, main.cpp:248-249) and copyOutput() copies the
+    renderer's own byte image device to device (renderer.cpp:888-891): both equal pixels()."""
+    import torch
+    scene = workloads.cornell_box(light="panel")
+    w, h = 80, 48
+    own = R.Renderer(scene, w, h)
+    for _ in range(3):
+        own.render()
+    want = own.pixels()
+    copied = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    own.copy_output(copied)
+    assert np.array_equal(copied.cpu().numpy(), want)
+    target = torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda")
+    other = R.Renderer(scene, w, h)
+    for _ in range(3):
+        other.render(target)
+    other.synchronize()
+    assert np.array_equal(target.cpu().numpy(), want)
+    assert np.array_equal(other.linear_pixels(), own.linear_pixels())
+    # the renderer's own byte image was never written by the second renderer; its view is the zero-copy one
+    view = R.device_view(own.output_buffer(), w * h * 4).view(h, w, 4)
+    assert np.array_equal(view.cpu().numpy(), want)
+
+
 def test_concurrent_tiles_do_not_change_the_image(R):
     """render() cut into 1, 2 or 5 concurrent parts (own streams, own wavefront state) gives bit-identical
     buffers; 72 rows exercise full 8-row bands, leftover rows and parts that start inside a band."""
