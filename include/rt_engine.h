@@ -52,8 +52,12 @@ size_t rt_photon_scan_storage(uint32_t bucketCount);
  * one bucket keep their input order (the reference leaves the order to an
  * atomic race, src/photon_grid.cu:36).  bucketCount must be a power of two.
  * If scanBytes is smaller than rt_photon_grid_scratch_bytes(count,
- * bucketCount) the library uses a cached workspace of its own.  count == 0 is
- * legal.  Runs on the default stream and synchronises the device before
+ * bucketCount) the library uses a cached workspace of its own, one per device:
+ * builds that fall back to it are ordered one behind the other by an event,
+ * whatever streams they are on, and a build that needs a larger workspace
+ * than the cached one synchronises the device while it is replaced.  Builds
+ * that bring their own scratch run concurrently on different streams.
+ * count == 0 is legal.  Runs on the default stream and synchronises the device before
  * returning (src/photon_grid.cu:82). */
 rt_status rt_build_photon_grid(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
                                uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted);
@@ -182,7 +186,14 @@ typedef struct rt_ray_hit {
     uint32_t primitive;
 } rt_ray_hit;
 
-/* n rays as two device arrays of float4: (origin, tmin) and (direction, tmax).
+/* The three queries below are enqueued on `stream` and return without waiting.
+ * Any number of them may be in flight on any number of streams and host
+ * threads: each launch draws its rays through a set of cursors of its own (the
+ * scene keeps a ring of sets; a launch that is dealt a set still in use makes
+ * its stream wait for the launch that holds it).  The scene and its BLASes must
+ * stay alive until the launches have finished.
+ *
+ * n rays as two device arrays of float4: (origin, tmin) and (direction, tmax).
  * A hit has tmin < t <= tmax; the closest hit is the smallest t, exact ties
  * going to the lowest (instance, primitive).  instance[i] = instanceId or
  * 0xffffffff. */

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace rt {
@@ -112,6 +113,13 @@ struct rt_scene {
     uint32_t hitGroupCount = 0;
     std::vector<float> inverses;            // 12 floats per instance (host copy)
     float buildMilliseconds = 0.0f;
-    uint32_t* feedCursors = nullptr;        // kFeedSlots sets of ray-feed cursors for the batched queries
-    mutable std::atomic<uint32_t> feedNext{0};
+    // kFeedSlots sets of ray-feed cursors for the batched queries.  A set is handed to one launch at a
+    // time: the event of a slot is recorded behind the kernel that uses it, and the next launch that is
+    // dealt the slot makes its stream wait for that event before it zeroes the cursors, so launches on
+    // different streams never share a set however many are in flight.
+    uint32_t* feedCursors = nullptr;
+    mutable hipEvent_t feedEvents[rt::kFeedSlots] = {};
+    mutable bool feedEventRecorded[rt::kFeedSlots] = {};
+    mutable uint32_t feedNext = 0;
+    mutable std::mutex feedMutex;
 };

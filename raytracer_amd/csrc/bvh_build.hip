@@ -1142,6 +1142,8 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->nodes), sizeof(WideNode) * builder.nodes.size()));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * count));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->feedCursors), sizeof(uint32_t) * kFeedWords * kFeedSlots));
+    for (hipEvent_t& event : scene->feedEvents)
+        RT_HIP(hipEventCreateWithFlags(&event, hipEventDisableTiming));
     RT_HIP(hipMemcpyAsync(scene->nodes, builder.nodes.data(), sizeof(WideNode) * builder.nodes.size(),
                           hipMemcpyHostToDevice, stream));
     RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice,
@@ -1234,6 +1236,9 @@ void rt_scene_destroy(rt_scene* scene) {
         (void)hipFree(scene->instances);
     if (scene->feedCursors)
         (void)hipFree(scene->feedCursors);
+    for (hipEvent_t event : scene->feedEvents)
+        if (event)
+            (void)hipEventDestroy(event);
     if (scene->shadeInstances)
         (void)hipFree(scene->shadeInstances);
     if (scene->hitGroups)

@@ -158,31 +158,41 @@ GridScratch carve(void* scratch, uint32_t maxCount) {
 
 // Workspace the library owns, per device, grown on demand, for callers whose
 // scratch buffer is smaller than the sort needs.
+// One build uses it at a time: `busy` is recorded behind the last kernel of the build that holds the
+// workspace, and the next build - on whatever stream - makes its stream wait for it first, so builds
+// on different streams that fall back to this workspace run one after the other instead of sorting
+// into each other's arrays.
 struct Workspace {
     void* data = nullptr;
     size_t bytes = 0;
+    hipEvent_t busy = nullptr;
+    bool recorded = false;
 };
 std::mutex workspaceMutex;
 Workspace workspaces[64];
 
-rt_status ownedWorkspace(size_t bytes, void** out) {
+// Called with workspaceMutex held.
+rt_status ownedWorkspace(size_t bytes, hipStream_t stream, Workspace** out) {
     int device = 0;
     RT_HIP(hipGetDevice(&device));
     if (device < 0 || device >= 64)
         return failInvalid("device index");
-    std::lock_guard<std::mutex> lock(workspaceMutex);
     Workspace& w = workspaces[device];
+    if (!w.busy)
+        RT_HIP(hipEventCreateWithFlags(&w.busy, hipEventDisableTiming));
     if (w.bytes < bytes) {
         if (w.data) {
-            RT_HIP(hipDeviceSynchronize());
+            RT_HIP(hipDeviceSynchronize());  // nothing may still be sorting in the block that is freed
             RT_HIP(hipFree(w.data));
             w.data = nullptr;
             w.bytes = 0;
         }
         RT_HIP(hipMalloc(&w.data, bytes));
         w.bytes = bytes;
+    } else if (w.recorded) {
+        RT_HIP(hipStreamWaitEvent(stream, w.busy, 0));
     }
-    *out = w.data;
+    *out = &w;
     return RT_SUCCESS;
 }
 
@@ -235,8 +245,13 @@ rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, ui
         return failInvalid("photons / sorted is null");
     const size_t needed = scratchBytes(count, bucketCount);
     void* workspace = scan;
-    if (!scan || scanBytes < needed)
-        RT_TRY(ownedWorkspace(needed, &workspace));
+    Workspace* owned = nullptr;
+    std::unique_lock<std::mutex> lock(workspaceMutex, std::defer_lock);
+    if (!scan || scanBytes < needed) {
+        lock.lock();
+        RT_TRY(ownedWorkspace(needed, stream, &owned));
+        workspace = owned->data;
+    }
     const GridScratch s = carve(workspace, count);
 
     hipLaunchKernelGGL(photonKeysKernel, dim3(stridedGrid(count, 256)), dim3(256), 0, stream,
@@ -254,6 +269,10 @@ rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, ui
     hipLaunchKernelGGL(photonReorderKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, photons, s.idx[result],
                        count, sorted);
     RT_HIP(hipGetLastError());
+    if (owned) {
+        RT_HIP(hipEventRecord(owned->busy, stream));
+        owned->recorded = true;
+    }
     return RT_SUCCESS;
 }
 

@@ -64,21 +64,17 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     }
 }
 
-// A zeroed set of feed cursors for one launch on `stream`.  The scene owns a
-// small ring of sets, so a few launches on different streams may overlap.
-rt_status feedCursors(const rt_scene* scene, hipStream_t stream, uint32_t** cursors) {
-    const uint32_t slot = scene->feedNext.fetch_add(1U, std::memory_order_relaxed) % kFeedSlots;
-    *cursors = scene->feedCursors + slot * kFeedWords;
-    RT_HIP(hipMemsetAsync(*cursors, 0, kFeedWords * sizeof(uint32_t), stream));
-    return RT_SUCCESS;
-}
-
 template <bool ANY, bool COUNT>
 rt_status launchTrace(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax, uint32_t n,
                       rt_ray_hit* hits, uint32_t* instance, uint8_t* occluded, uint64_t* counters4, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    uint32_t* cursors = nullptr;
-    RT_TRY(feedCursors(scene, s, &cursors));
+    // one slot of the scene's ring of cursor sets, private to this launch (see rt_scene::feedEvents)
+    std::lock_guard<std::mutex> lock(scene->feedMutex);
+    const uint32_t slot = scene->feedNext++ % kFeedSlots;
+    if (scene->feedEventRecorded[slot])
+        RT_HIP(hipStreamWaitEvent(s, scene->feedEvents[slot], 0));
+    uint32_t* cursors = scene->feedCursors + slot * kFeedWords;
+    RT_HIP(hipMemsetAsync(cursors, 0, kFeedWords * sizeof(uint32_t), s));
     const uint32_t blocks = std::min<uint32_t>(divUp(n, kTraceBlock), persistentBlocks(scene->device));
     hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
                        static_cast<uint32_t>(scene->nodeCount), scene->instances, scene->instanceCount,
@@ -86,6 +82,8 @@ rt_status launchTrace(const rt_scene* scene, const rt_float4* originTmin, const 
                        reinterpret_cast<uint4*>(hits), instance, occluded,
                        reinterpret_cast<unsigned long long*>(counters4), cursors);
     RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(scene->feedEvents[slot], s));
+    scene->feedEventRecorded[slot] = true;
     return RT_SUCCESS;
 }
 

@@ -269,6 +269,18 @@ std::int64_t indexOr(const Json* object, std::string_view key, std::int64_t fall
     const Json* v = object ? object->find(key) : nullptr;
     return v && v->isNumber() ? static_cast<std::int64_t>(v->number) : fallback;
 }
+// A byte offset, length, stride or element count: a non-negative whole number below 2^53 (what a
+// JSON number holds exactly).  Anything else - negative, fractional, huge, NaN - is refused rather
+// than cast: a negative offset turned into a size_t would wrap and slip past every bounds check.
+std::size_t sizeOr(const Json* object, std::string_view key, std::size_t fallback) {
+    const Json* v = object ? object->find(key) : nullptr;
+    if (!v || !v->isNumber())
+        return fallback;
+    const double n = v->number;
+    if (!(n >= 0.0) || n > 9007199254740992.0 || n != std::floor(n))
+        throw error("Expected a non-negative whole number", std::string(key));
+    return static_cast<std::size_t>(n);
+}
 std::string stringOr(const Json* object, std::string_view key, std::string fallback = {}) {
     const Json* v = object ? object->find(key) : nullptr;
     return v && v->isString() ? v->text : fallback;
@@ -666,9 +678,16 @@ struct AccessorReader {
             throw error("Buffer index out of range");
         const auto& buffer = asset.buffers[view.buffer];
         stride = view.stride ? view.stride : element;
-        const std::size_t begin = view.offset + accessor.offset;
-        if (accessor.count > 0 && begin + stride * (accessor.count - 1) + element > buffer.size())
+        // no sum or product here may wrap: every term is compared against what is left of the buffer
+        const std::size_t size = buffer.size();
+        if (view.offset > size || accessor.offset > size - view.offset)
             throw error("Accessor reaches past the end of its buffer");
+        const std::size_t begin = view.offset + accessor.offset;
+        if (accessor.count > 0) {
+            const std::size_t room = size - begin;
+            if (element > room || (accessor.count - 1) > (room - element) / stride)
+                throw error("Accessor reaches past the end of its buffer");
+        }
         base = buffer.data() + begin;
     }
 
@@ -796,18 +815,19 @@ Asset openAsset(const std::filesystem::path& path) {
         } else {
             asset.buffers.push_back(loadUri(uri, asset.directory, nullptr));
         }
-        const std::size_t declared = static_cast<std::size_t>(indexOr(&b, "byteLength", 0));
+        const std::size_t declared = sizeOr(&b, "byteLength", 0);
         if (asset.buffers.back().size() < declared)
             throw error("Buffer is shorter than its byteLength", uri);
         ++bufferIndex;
     }
     for (const Json& v : arrayOf(asset.root, "bufferViews")) {
         BufferView view;
-        view.buffer = static_cast<std::size_t>(indexOr(&v, "buffer", 0));
-        view.offset = static_cast<std::size_t>(indexOr(&v, "byteOffset", 0));
-        view.length = static_cast<std::size_t>(indexOr(&v, "byteLength", 0));
-        view.stride = static_cast<std::size_t>(indexOr(&v, "byteStride", 0));
-        if (view.buffer >= asset.buffers.size() || view.offset + view.length > asset.buffers[view.buffer].size())
+        view.buffer = sizeOr(&v, "buffer", 0);
+        view.offset = sizeOr(&v, "byteOffset", 0);
+        view.length = sizeOr(&v, "byteLength", 0);
+        view.stride = sizeOr(&v, "byteStride", 0);
+        if (view.buffer >= asset.buffers.size() || view.offset > asset.buffers[view.buffer].size() ||
+            view.length > asset.buffers[view.buffer].size() - view.offset)
             throw error("Buffer view reaches past the end of its buffer", path.string());
         asset.views.push_back(view);
     }
@@ -816,8 +836,10 @@ Asset openAsset(const std::filesystem::path& path) {
             throw error("Sparse accessors are not supported", path.string());
         Accessor accessor;
         accessor.view = indexOr(&a, "bufferView", -1);
-        accessor.offset = static_cast<std::size_t>(indexOr(&a, "byteOffset", 0));
-        accessor.count = static_cast<std::size_t>(indexOr(&a, "count", 0));
+        accessor.offset = sizeOr(&a, "byteOffset", 0);
+        accessor.count = sizeOr(&a, "count", 0);
+        if (accessor.count > 0xffffffffULL)  // vertices and indices are addressed with 32 bits
+            throw error("Accessor has too many elements", path.string());
         accessor.componentType = static_cast<int>(indexOr(&a, "componentType", 5126));
         accessor.components = componentsOf(stringOr(&a, "type", "SCALAR"));
         accessor.normalized = boolOr(&a, "normalized", false);

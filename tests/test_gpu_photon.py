@@ -183,3 +183,24 @@ def test_full_size_properties(engine, oracle):
     flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
     ref = oracle.photon_gather(grid.sorted.cpu().numpy(), off.astype(np.uint32), B, r, qp, qn, threads=8)
     assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
+
+
+def test_builds_on_two_streams_through_the_library_workspace(engine, oracle):
+    """Grid builds without scratch of their own fall back to one workspace per device; issued back to back
+    on two streams they are ordered one behind the other and every grid comes out right (they used to
+    sort into each other's arrays)."""
+    import torch
+    B = 1 << 14
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cases = []
+    for k, n in enumerate((200000, 190000, 50000, 210000, 1000, 205000)):
+        ph = workloads.caustic_photons(n, seed=30 + k)
+        cases.append((ph, dev(ph), engine.PhotonGrid(n, B, own_scratch=False)))
+    torch.cuda.synchronize()
+    for k, (ph, dph, grid) in enumerate(cases):
+        grid.build(dph, 0.004, stream=streams[k % 2])
+    torch.cuda.synchronize()
+    for ph, dph, grid in cases:
+        offsets, srt = oracle.build_photon_grid(ph, 0.004, B)
+        assert np.array_equal(u32(grid.offsets), offsets)
+        assert np.array_equal(grid.sorted[:len(ph)].cpu().numpy().view(np.uint32), srt.view(np.uint32))

@@ -293,3 +293,39 @@ def test_tree_deeper_than_the_traversal_stack_is_refused(engine):
     assert top.stats().maxDepth <= 18
     o, d = workloads.random_rays(shallow, 1000, seed=1)
     top.trace_closest(dev(o), dev(d))
+
+
+def test_many_launches_in_flight_on_two_streams(engine):
+    """More batched queries in flight than the scene keeps cursor sets for (16), alternating between two
+    streams with nothing waited for in between: every launch still draws its rays through a set of its
+    own, so every batch equals what the same batch gives alone.  Long batches next to short ones make
+    the launches overlap in time."""
+    import torch
+    scene = workloads.dragon_cornell()
+    top, blases = engine_scene(engine, scene)
+    o, d = workloads.random_rays(scene, 600000, seed=14)
+    o, d = dev(o), dev(d)
+    cuts = [0]
+    rng = np.random.default_rng(2)
+    while cuts[-1] < o.shape[0]:
+        cuts.append(min(o.shape[0], cuts[-1] + int(rng.choice([300, 5000, 60000]))))
+    batches = [(o[a:b].contiguous(), d[a:b].contiguous()) for a, b in zip(cuts, cuts[1:])]
+    assert len(batches) > 40
+    want = [top.trace_closest(bo, bd) for bo, bd in batches]
+    want_any = [top.trace_any(bo, bd) for bo, bd in batches]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got, got_any = [], []
+    for k, (bo, bd) in enumerate(batches):
+        hits = torch.empty((bo.shape[0], 4), dtype=torch.float32, device="cuda")
+        inst = torch.empty(bo.shape[0], dtype=torch.int32, device="cuda")
+        occ = torch.empty(bo.shape[0], dtype=torch.uint8, device="cuda")
+        top.trace_closest(bo, bd, stream=streams[k % 2], hits=hits, inst=inst)
+        top.trace_any(bo, bd, stream=streams[(k + 1) % 2], out=occ)
+        got.append((hits, inst))
+        got_any.append(occ)
+    torch.cuda.synchronize()
+    for k in range(len(batches)):
+        assert torch.equal(got[k][0].view(torch.int32), want[k][0].view(torch.int32)), k
+        assert torch.equal(got[k][1], want[k][1]), k
+        assert torch.equal(got_any[k], want_any[k]), k

@@ -212,6 +212,34 @@ def test_error_messages(R, tmp_path):
                meshes=[{"name": "m", "primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}])
     with pytest.raises(engine.EngineError, match="Invalid triangle indices: m.0"):
         load(doc)
+    # offsets, lengths and counts that would wrap when cast or summed: a negative byteOffset, a fractional
+    # one, a count whose stride * (count - 1) overflows 64 bits, an accessor offset past its view, a view
+    # whose offset + length wraps
+    import copy
+
+    def broken(change):
+        d = copy.deepcopy(doc)
+        d["accessors"][1] = {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}
+        change(d)
+        return d
+
+    for change, message in (
+            (lambda d: d["bufferViews"][0].update(byteOffset=-1, byteLength=1), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(byteOffset=-16), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(byteOffset=1.5), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(count=-3), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(count=2 ** 70), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(count=(2 ** 64) // 12 + 2), "non-negative whole number"),
+            (lambda d: d["accessors"][0].update(count=2 ** 52), "too many elements"),
+            (lambda d: d["accessors"][0].update(count=2 ** 31), "reaches past the end"),
+            (lambda d: (d["bufferViews"][0].update(byteStride=2 ** 40), d["accessors"][0].update(count=2 ** 30)),
+             "reaches past the end"),
+            (lambda d: d["accessors"][0].update(byteOffset=40), "reaches past the end"),
+            (lambda d: d["bufferViews"][1].update(byteOffset=2 ** 53, byteLength=6), "reaches past the end"),
+            (lambda d: d["bufferViews"][1].update(byteOffset=40, byteLength=2 ** 53), "reaches past the end"),
+            (lambda d: (d["accessors"][0].pop("bufferView"), d["accessors"][0].update(count=2 ** 40)), "too many elements")):
+        with pytest.raises(engine.EngineError, match=message):
+            load(broken(change))
 
 
 def png_reference(data):
