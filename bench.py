@@ -33,6 +33,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if os.environ.get("RT_BENCH_ROOT"):  # development aid: a side-by-side build of the package (tools/variants.sh)
+    sys.path.insert(0, os.path.abspath(os.environ["RT_BENCH_ROOT"]))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 NODE_BYTES, TRIANGLE_BYTES, RAY_IO_BYTES = 80.0, 36.0, 52.0  # algorithmic bytes: wide node, 3 x float3, ray in + hit out

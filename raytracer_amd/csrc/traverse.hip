@@ -18,6 +18,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
                                                            uint32_t* cursors) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
+    __shared__ LeafShare leafShare[kTraceBlock / 64];
 
     uint32_t spillRef[kPrivateStack];
     float spillT[kPrivateStack];
@@ -26,13 +27,12 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     RayFeed feed(cursors, n);
     unsigned long long rays = 0;
     tracePersistent<COUNT>(
-        walk, feed,
-        [&](uint32_t ray, Traversal<COUNT>& w) {
-            const float4 o4 = originTmin[ray];
-            const float4 d4 = directionTmax[ray];
+        walk, feed, leafShare[threadIdx.x >> 6],
+        [&](uint32_t ray) { return RayIn{originTmin[ray], directionTmax[ray], make_uint2(kNoHit, kNoHit)}; },
+        [&](uint32_t, const RayIn& in, Traversal<COUNT>& w) {
+            const float4 o4 = in.origin, d4 = in.direction;
             w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit, ANY);
             ++rays;
-            return true;
         },
         [&](uint32_t ray, const TraceResult& r) {
             const bool found = r.primitive != kNoHit;

@@ -38,13 +38,31 @@ namespace rt {
 #endif
 // Persistent launches: how many idle lanes make a wave fetch new rays.
 #ifndef RT_TRACE_REFILL
-#define RT_TRACE_REFILL 32
+#define RT_TRACE_REFILL 24
 #endif
 // Triangles a lane may test per turn.
 #ifndef RT_TRACE_LEAF_STEPS
 #define RT_TRACE_LEAF_STEPS 2
 #endif
 // Workgroups launched per resident workgroup slot (1 = exactly one resident set).
+// Whether a lane takes a stack entry a second time per turn, behind the leaf code.
+#ifndef RT_TRACE_POP_AFTER_LEAF
+#define RT_TRACE_POP_AFTER_LEAF 1
+#endif
+// Whether the triangles of the leaves a wave's lanes have reached are tested by all 64 lanes together
+// (one triangle per lane) instead of by the few lanes that own the leaves, one triangle after the other.
+// Off: measured on MI355X the shared phase is slower (3.75 against 3.49 ms per 1080p step even at four
+// waves per SIMD where it does not spill; at five waves it spills 40 registers): publishing the rays,
+// dealing out the triangles and collecting the results through LDS costs every lane of the wave more
+// instructions and two more LDS round trips per turn than the few owners' own tests cost.
+#ifndef RT_TRACE_SHARED_LEAVES
+#define RT_TRACE_SHARED_LEAVES 0
+#endif
+// Whether a refill rides along a turn (the atomic that draws ray indices travels during the node
+// step, the ray loads during the stack and leaf steps) instead of stalling the wave twice.
+#ifndef RT_TRACE_RIDING_REFILL
+#define RT_TRACE_RIDING_REFILL 1
+#endif
 #ifndef RT_TRACE_GRID_SCALE
 #define RT_TRACE_GRID_SCALE 1
 #endif
@@ -504,6 +522,45 @@ struct Traversal {
         node = 0;
     }
 
+    // Shared leaf phase, owner side: whether this lane stands at a bottom-level leaf whose triangles
+    // are all inside the triangle array (a leaf that is not ends the ray, as triangleStep would).
+    __device__ __forceinline__ bool atTriangles() {
+        if (!((node & kLeafBit) && node < kPop && inBottom))
+            return false;
+        const uint32_t count = (node >> 28) & 7U, first = node & 0x0fffffffU;
+        if (first + count > itemLimit || count == 0U) {
+            ++violations;
+            found = false;
+            node = kDone;
+            return false;
+        }
+        return true;
+    }
+    // What a lane that tests one of this lane's triangles needs to know.
+    __device__ __forceinline__ void publish(uint4 (&record)[3]) const {
+        const uintptr_t base = reinterpret_cast<uintptr_t>(triangles);
+        record[0] = make_uint4(__float_as_uint(cur.ox), __float_as_uint(cur.oy), __float_as_uint(cur.oz), __float_as_uint(tmin));
+        record[1] = make_uint4(__float_as_uint(shear.Sx), __float_as_uint(shear.Sy), __float_as_uint(shear.Sz),
+                               __float_as_uint(bestT));
+        record[2] = make_uint4(static_cast<uint32_t>(shear.kx | shear.ky << 2 | shear.kz << 4), static_cast<uint32_t>(base),
+                               static_cast<uint32_t>(base >> 32), node & 0x0fffffffU);
+    }
+    // One tested triangle comes back: the closest hit is the least (t, instance, primitive), whatever
+    // order the triangles are taken in.
+    __device__ __forceinline__ void accept(const uint4& r) {
+        if (r.w == kNoHit)
+            return;
+        const float t = __uint_as_float(r.x);
+        if (t < bestT || (t == bestT && (instanceId < bestInst || (instanceId == bestInst && r.w < bestPrim)))) {
+            bestT = t;
+            bestU = __uint_as_float(r.y);
+            bestV = __uint_as_float(r.z);
+            bestPrim = r.w;
+            bestInst = instanceId;
+            found = true;
+        }
+    }
+
     // Bottom-level leaf: tests its next triangle.  The leaf reference counts down;
     // after the last triangle the lane moves on to the next stack entry.
     __device__ __forceinline__ void triangleStep() {
@@ -537,6 +594,15 @@ struct Traversal {
     }
 };
 
+// Scratch of one wave for the shared leaf phase (tracePersistent): the rays of up to kShareOwners lanes
+// whose walk stands at a leaf, which (owner, triangle) each of the 64 lanes tests, and what it found.
+constexpr int kShareOwners = 16;
+struct LeafShare {
+    uint4 ray[kShareOwners][3];  // (origin, tmin), (Sx, Sy, Sz, tmax), (kx | ky << 2 | kz << 4, triangles lo, hi, first)
+    uint4 found[64];             // t, u, v, primitive (kNoHit: no hit)
+    uint32_t item[64];           // owner slot << 2 | triangle of the leaf
+};
+
 // Hands out ray indices [0, n) to the waves of a persistent launch.  The range
 // is cut into eight contiguous chunks, one per XCD (workgroups are dealt to the
 // XCDs round-robin, so blockIdx & 7 names the XCD): a wave drains the chunk of
@@ -568,6 +634,30 @@ struct RayFeed {
         return rank >= (end - begin + 63U) / 64U + 2U;
     }
 
+    // take() in two halves, so that the answer of the atomic can travel while the wave does other
+    // work.  ask(): one atomic for `want` indices of the current chunk; what it returns goes to
+    // answer(), which hands the indices to the lanes of `idleMask` or, when the chunk had nothing
+    // left, moves on to the next chunk and returns false (the caller asks again next time).
+    __device__ __forceinline__ uint32_t ask(uint32_t want) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0)
+            base = atomicAdd(&cursors[chunk * kFeedStride], want);
+        return base;
+    }
+    __device__ __forceinline__ bool answer(uint32_t ticket, unsigned long long idleMask, bool idle, uint32_t& index) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t begin = min(chunk * chunkSize, n), end = min(begin + chunkSize, n);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(ticket);
+        if (base < end - begin) {
+            const uint32_t mine = begin + base + __popcll(idleMask & ((1ULL << lane) - 1ULL));
+            index = mine;
+            return idle && mine < end;
+        }
+        exhausted = __builtin_amdgcn_readfirstlane(exhausted + 1U);
+        chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) & 7U);
+        return false;
+    }
+
     // Every lane of the wave calls this with the same `idleMask` (lanes that want
     // a ray).  Returns true with `index` set for the lanes that got one.
     __device__ __forceinline__ bool take(unsigned long long idleMask, bool idle, uint32_t& index) {
@@ -591,15 +681,54 @@ struct RayFeed {
     }
 };
 
-// Persistent traversal loop of one lane.  fetch(index, traversal) loads ray
-// `index` and calls traversal.begin(...), returning false when the ray needs no
-// walk; store(index, result) consumes a finished ray.
+// Shared leaf phase, tester side: the triangle `item` names, against the ray its owner published.
+__device__ __forceinline__ uint4 testShared(const LeafShare& share, uint32_t item) {
+    const uint4 r0 = share.ray[item >> 2][0], r1 = share.ray[item >> 2][1], r2 = share.ray[item >> 2][2];
+    Ray ray;
+    ray.ox = __uint_as_float(r0.x);
+    ray.oy = __uint_as_float(r0.y);
+    ray.oz = __uint_as_float(r0.z);
+    ray.dx = ray.dy = ray.dz = 0.0f;  // the test works from the sheared ray
+    Shear shear;
+    shear.kx = static_cast<int>(r2.x & 3U);
+    shear.ky = static_cast<int>((r2.x >> 2) & 3U);
+    shear.kz = static_cast<int>((r2.x >> 4) & 3U);
+    shear.Sx = __uint_as_float(r1.x);
+    shear.Sy = __uint_as_float(r1.y);
+    shear.Sz = __uint_as_float(r1.z);
+    const PackedTriangle* triangles =
+        reinterpret_cast<const PackedTriangle*>(static_cast<uintptr_t>(r2.y) | static_cast<uintptr_t>(r2.z) << 32);
+    GlobalUint4 tp = globalView(triangles + (r2.w + (item & 3U)));
+    const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+    float t, u, v;
+    if (!intersectTriangle(ray, shear, p0, p1, p2, __uint_as_float(r0.w), __uint_as_float(r1.w), t, u, v))
+        return make_uint4(0U, 0U, 0U, kNoHit);
+    return make_uint4(__float_as_uint(t), __float_as_uint(u), __float_as_uint(v), p0.w);
+}
+
+// Orders the LDS traffic of one wave: what lanes wrote before it, other lanes of the wave read after it.
+__device__ __forceinline__ void waveSync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A ray as it comes out of memory, before a lane's walk takes it over.
+struct RayIn {
+    float4 origin, direction;  // (origin, tmin), (direction, tmax)
+    uint2 target;              // candidate (instance, primitive) a shadow ray starts with
+};
+
+// Persistent traversal loop of one lane.  load(index) reads ray `index`;
+// start(index, ray, traversal) calls traversal.begin(...); store(index, result)
+// consumes a finished ray.
 //
 // Per turn every lane with a ray does at most one wide node, one stack entry
 // and one leaf (up to RT_TRACE_LEAF_STEPS triangles of it), so the lanes of a
 // wave run the node code together and the leaf code together.
-template <bool COUNT, typename Fetch, typename Store>
-__device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Fetch&& fetch, Store&& store) {
+template <bool COUNT, typename Load, typename Start, typename Store>
+__device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, LeafShare& share, Load&& load,
+                                                Start&& start, Store&& store) {
     bool active = false;
     uint32_t rayIndex = 0;
 #ifdef RT_TRACE_PROFILE
@@ -621,13 +750,26 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
         }
 #endif
         const unsigned long long idleMask = __ballot(!active);
+#if RT_TRACE_RIDING_REFILL
+        // A refill rides along the turn: the atomic is sent here and read behind the node step,
+        // the rays are loaded there and taken over at the end of the turn, so the two round trips
+        // to memory overlap with the ones the walk makes anyway.
+        const bool refilling = !feed.drained() && __popcll(idleMask) >= RT_TRACE_REFILL;
+        uint32_t ticket = 0;
+        if (refilling)
+            ticket = feed.ask(__popcll(idleMask));
+        if (__ballot(active) == 0ULL && !refilling) {
+            if (feed.drained())
+                break;
+            continue;
+        }
+#else
         if (!feed.drained() && __popcll(idleMask) >= RT_TRACE_REFILL) {
             uint32_t index = 0;
             if (feed.take(idleMask, !active, index)) {
-                if (fetch(index, walk)) {
-                    active = true;
-                    rayIndex = index;
-                }
+                start(index, load(index), walk);
+                active = true;
+                rayIndex = index;
             }
         }
         if (__ballot(active) == 0ULL) {
@@ -635,6 +777,7 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
                 break;
             continue;
         }
+#endif
         if (active) {
 #ifdef RT_TRACE_PROFILE
             float* profile = walk.profile;
@@ -648,18 +791,82 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             // (three nodes per turn spilt 26-48 registers; this form spills none).
             if (!(walk.node & kLeafBit))
                 walk.nodeStep();
+#if RT_TRACE_RIDING_REFILL
+        }
+        bool taking = false;
+        uint32_t incoming = 0;
+        RayIn next{};
+        if (refilling) {
+            taking = feed.answer(ticket, idleMask, !active, incoming);
+            if (taking)
+                next = load(incoming);
+        }
+        if (active) {
+#endif
             if (walk.node == kPop)
                 walk.node = walk.pop();
             if ((walk.node & kLeafBit) && walk.node < kPop) {
                 if (!walk.inBottom) {
                     walk.enterInstance();
-                } else {
+                }
+#if !RT_TRACE_SHARED_LEAVES
+                else {
                     const uint32_t count = min((walk.node >> 28) & 7U, static_cast<uint32_t>(RT_TRACE_LEAF_STEPS));
                     for (uint32_t k = 0; k < count && walk.node < kPop; ++k)
                         walk.triangleStep();
                 }
+#endif
             }
+#if RT_TRACE_POP_AFTER_LEAF && !RT_TRACE_SHARED_LEAVES
+            // a lane whose leaf is done takes its next stack entry at once, so that it starts the
+            // next turn at a node instead of spending that turn's node step idle
+            if (walk.node == kPop)
+                walk.node = walk.pop();
+#endif
         }
+#if RT_TRACE_SHARED_LEAVES
+        // The leaf phase is the wave's, not the lane's: the lanes that stand at a leaf (typically a
+        // handful, each with one to four triangles) publish their rays, the triangles are dealt out
+        // one per lane over all 64 lanes, idle ones included, tested in one go, and the owners take
+        // the results back in triangle order.  A leaf is finished in the turn it is reached.
+        {
+            const int lane = threadIdx.x & 63;
+            const unsigned long long below = (1ULL << lane) - 1ULL;
+            bool wants = active && walk.atTriangles();
+            unsigned long long waiting = __ballot(wants);
+            while (waiting) {
+                const uint32_t slot = __popcll(waiting & below);
+                const bool owner = wants && slot < static_cast<uint32_t>(kShareOwners);
+                const uint32_t count = owner ? (walk.node >> 28) & 7U : 0U;
+                // triangles before this lane's: counts are at most 4, three ballots carry them
+                const unsigned long long c0 = __ballot(count & 1U), c1 = __ballot(count & 2U), c2 = __ballot(count & 4U);
+                const uint32_t before = __popcll(c0 & below) + 2U * __popcll(c1 & below) + 4U * __popcll(c2 & below);
+                const uint32_t total = __popcll(c0) + 2U * __popcll(c1) + 4U * __popcll(c2);
+                if (owner) {
+                    walk.publish(share.ray[slot]);
+                    for (uint32_t k = 0; k < count; ++k)
+                        share.item[before + k] = slot << 2 | k;
+                    if (COUNT)
+                        walk.counters.triangles += count;
+                }
+                waveSync();
+                if (static_cast<uint32_t>(lane) < total)
+                    share.found[lane] = testShared(share, share.item[lane]);
+                waveSync();
+                if (owner) {
+                    for (uint32_t k = 0; k < count; ++k)
+                        walk.accept(share.found[before + k]);
+                    walk.node = walk.anyHit && walk.found ? kDone : kPop;
+                    wants = false;
+                }
+                waiting = __ballot(wants);
+            }
+#if RT_TRACE_POP_AFTER_LEAF
+            if (active && walk.node == kPop)
+                walk.node = walk.pop();
+#endif
+        }
+#endif
         if (active && walk.node == kDone) {
             store(rayIndex, walk.result());
             active = false;
@@ -667,6 +874,13 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             walk.finishRay();
 #endif
         }
+#if RT_TRACE_RIDING_REFILL
+        if (taking) {
+            start(incoming, next, walk);
+            active = true;
+            rayIndex = incoming;
+        }
+#endif
     }
 #ifdef RT_TRACE_PROFILE
     walk.flushProfile();

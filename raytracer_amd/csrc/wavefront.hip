@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
                                                            Buffers b, int which, int withShadow, uint2 limits) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
+    __shared__ LeafShare leafShare[kTraceBlock / 64];
     uint32_t spillRef[kPrivateStack];
     float spillT[kPrivateStack];
     Traversal<COUNT> walk(topNodes, limits.x, instances, limits.y, ldsView(&stackRef[0][threadIdx.x]),
@@ -221,20 +222,17 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     const float4* origins = b.rayOrigin[which >= 0 ? which : 0];
     const float4* directions = b.rayDirection[which >= 0 ? which : 0];
     tracePersistent<COUNT>(
-        walk, feed,
-        [&](uint32_t index, Traversal<COUNT>& w) {
-            if (index < extendCount) {
-                const float4 o4 = origins[index];
-                const float4 d4 = directions[index];
-                w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, kNoHit, kNoHit, false);
-                return true;
-            }
+        walk, feed, leafShare[threadIdx.x >> 6],
+        [&](uint32_t index) {
+            if (index < extendCount)
+                return RayIn{origins[index], directions[index], make_uint2(kNoHit, kNoHit)};
             const uint32_t ray = index - extendCount;
-            const float4 o4 = b.shadowOrigin[ray];
-            const float4 d4 = b.shadowDirection[ray];
-            const uint2 target = b.shadowTarget[ray];  // kNoHit ids unless the ray is aimed at an emissive triangle
-            w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, target.x, target.y, true);
-            return true;
+            // kNoHit ids unless the ray is aimed at an emissive triangle
+            return RayIn{b.shadowOrigin[ray], b.shadowDirection[ray], b.shadowTarget[ray]};
+        },
+        [&](uint32_t index, const RayIn& in, Traversal<COUNT>& w) {
+            const float4 o4 = in.origin, d4 = in.direction;
+            w.begin(Ray{o4.x, o4.y, o4.z, d4.x, d4.y, d4.z}, o4.w, d4.w, in.target.x, in.target.y, index >= extendCount);
         },
         [&](uint32_t index, const TraceResult& r) {
             if (index < extendCount) {

@@ -308,7 +308,7 @@ def test_many_launches_in_flight_on_two_streams(engine):
     cuts = [0]
     rng = np.random.default_rng(2)
     while cuts[-1] < o.shape[0]:
-        cuts.append(min(o.shape[0], cuts[-1] + int(rng.choice([300, 5000, 60000]))))
+        cuts.append(min(o.shape[0], cuts[-1] + int(rng.choice([300, 5000, 25000]))))
     batches = [(o[a:b].contiguous(), d[a:b].contiguous()) for a, b in zip(cuts, cuts[1:])]
     assert len(batches) > 40
     want = [top.trace_closest(bo, bd) for bo, bd in batches]
