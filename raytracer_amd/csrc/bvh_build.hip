@@ -396,6 +396,94 @@ __global__ __launch_bounds__(256) void iotaKernel(uint32_t* out, uint32_t n, uin
         out[i] = base + i;
 }
 
+// ---- 3c. surface-area refinement of the upper levels --------------------------
+//
+// The radix tree splits space where the Morton code says, which is blind to how the triangles
+// are spread.  Its subtrees of at most `limit` triangles are therefore kept as they are
+// ("clusters"), and the tree above them is rebuilt top-down with the binned surface-area
+// heuristic (16 bins per axis, cost = box area x triangles on either side): the top of the tree
+// is where a poor cut costs most, and with a few thousand clusters it is small enough to build
+// on the host while the device holds the rest.  Leaves are then renumbered in depth-first order
+// of the new tree (the kernels of section 3b), so that every subtree still covers a contiguous
+// range of the triangle order, which the collapse relies on.
+
+__device__ inline uint32_t trianglesBelow(uint32_t id, uint32_t n, const uint32_t* first, const uint32_t* last) {
+    return id >= n - 1U ? 1U : last[id] - first[id] + 1U;
+}
+
+// marks[k] = 1 where the k-th sorted triangle is the first one of a cluster, roots[k] = that
+// cluster's node; upper[i] = 1 for the internal nodes above the clusters.  Each array ends with a
+// zero so that the exclusive scans yield the totals.
+__global__ __launch_bounds__(256) void clusterMarkKernel(uint32_t n, uint32_t limit, const uint32_t* parent,
+                                                         const uint32_t* first, const uint32_t* last, uint32_t* marks,
+                                                         uint32_t* roots, uint32_t* upper, uint32_t* counts) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2U * n - 1U)
+        return;
+    const uint32_t below = trianglesBelow(id, n, first, last);
+    if (id < n - 1U) {
+        upper[id] = below > limit ? 1U : 0U;
+        counts[id] = below;
+    }
+    if (id == n - 1U)
+        upper[id] = 0U;  // trailing zero (upper has n entries)
+    const uint32_t up = parent[id];
+    if (below <= limit && up != kNoHit && trianglesBelow(up, n, first, last) > limit) {
+        const uint32_t k = id >= n - 1U ? id - (n - 1U) : first[id];
+        marks[k] = 1U;
+        roots[k] = id;
+    }
+}
+
+struct ClusterRecord {
+    Box4 box;
+    uint32_t node, triangles, pad[2];
+};
+
+__global__ __launch_bounds__(256) void clusterGatherKernel(uint32_t n, const uint32_t* marks, const uint32_t* slots,
+                                                           const uint32_t* roots, const uint32_t* first,
+                                                           const uint32_t* last, const Box4* bounds,
+                                                           ClusterRecord* clusters) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || slots[k + 1U] == slots[k])
+        return;
+    (void)marks;
+    ClusterRecord record;
+    record.node = roots[k];
+    record.box = bounds[record.node];
+    record.triangles = trianglesBelow(record.node, n, first, last);
+    record.pad[0] = record.pad[1] = 0U;
+    clusters[slots[k]] = record;
+}
+
+__global__ __launch_bounds__(256) void upperIdsKernel(uint32_t n, const uint32_t* slots, uint32_t* ids) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n - 1U && slots[id + 1U] != slots[id])
+        ids[slots[id]] = id;
+}
+
+struct UpperNode {
+    Box4 box;
+    uint32_t id, left, right, triangles;
+};
+
+__global__ __launch_bounds__(256) void upperScatterKernel(const UpperNode* nodes, uint32_t count, uint32_t* left,
+                                                          uint32_t* right, uint32_t* parent, Box4* bounds,
+                                                          uint32_t* counts) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const UpperNode node = nodes[k];
+    left[node.id] = node.left;
+    right[node.id] = node.right;
+    parent[node.left] = node.id;
+    parent[node.right] = node.id;
+    bounds[node.id] = node.box;
+    counts[node.id] = node.triangles;
+    if (k == 0)
+        parent[node.id] = kNoHit;  // the root
+}
+
 // ---- 4. collapse into wide nodes --------------------------------------------
 
 struct Child {
@@ -636,6 +724,224 @@ struct DeviceBuffer {
     }
 };
 
+
+// ---- surface-area rebuild of the tree above the clusters (host) ----------------
+
+// Whether the upper levels are rebuilt (RT_BLAS_REFINE=0 keeps the plain radix tree, for comparison).
+static bool refineChoice() {
+    const char* v = std::getenv("RT_BLAS_REFINE");
+    return !(v && std::strcmp(v, "0") == 0);
+}
+
+struct HostBox {
+    float lo[3], hi[3];
+    void grow(const HostBox& o) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], o.lo[a]);
+            hi[a] = std::max(hi[a], o.hi[a]);
+        }
+    }
+    float area() const {
+        const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    }
+    static HostBox empty() { return {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}}; }
+};
+
+// Binary tree over the clusters by top-down binned surface-area splits.  Nodes come out in
+// pre-order (the root first), which is also the order the old upper nodes' ids are handed to
+// them in; a child reference is either an index into `nodes` or, with kClusterBit, a cluster.
+struct UpperBuilder {
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kClusterBit = 0x80000000U;
+    struct Node {
+        HostBox box;
+        uint32_t left, right, triangles;
+    };
+    const std::vector<ClusterRecord>& clusters;
+    std::vector<HostBox> boxes;
+    std::vector<uint32_t> order;
+    std::vector<Node> nodes;
+
+    explicit UpperBuilder(const std::vector<ClusterRecord>& c) : clusters(c), boxes(c.size()), order(c.size()) {
+        for (size_t i = 0; i < c.size(); ++i) {
+            boxes[i] = {{c[i].box.lo.x, c[i].box.lo.y, c[i].box.lo.z}, {c[i].box.hi.x, c[i].box.hi.y, c[i].box.hi.z}};
+            order[i] = static_cast<uint32_t>(i);
+        }
+        nodes.reserve(c.size());
+    }
+
+    // Builds the subtree over order[begin, end) and returns its reference.
+    uint32_t build(uint32_t begin, uint32_t end) {
+        if (end - begin == 1U)
+            return kClusterBit | order[begin];
+        HostBox all = HostBox::empty(), centres = HostBox::empty();
+        uint32_t triangles = 0;
+        for (uint32_t i = begin; i < end; ++i) {
+            const HostBox& b = boxes[order[i]];
+            all.grow(b);
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (b.lo[a] + b.hi[a]);
+                centres.lo[a] = std::min(centres.lo[a], c);
+                centres.hi[a] = std::max(centres.hi[a], c);
+            }
+            triangles += clusters[order[i]].triangles;
+        }
+        int bestAxis = -1, bestBin = 0;
+        float bestCost = INFINITY;
+        for (int axis = 0; axis < 3; ++axis) {
+            const float extent = centres.hi[axis] - centres.lo[axis];
+            if (!(extent > 0.0f))
+                continue;
+            HostBox binBox[kBins];
+            uint32_t binCount[kBins] = {};
+            for (auto& b : binBox)
+                b = HostBox::empty();
+            const float scale = static_cast<float>(kBins) / extent;
+            for (uint32_t i = begin; i < end; ++i) {
+                const HostBox& b = boxes[order[i]];
+                const int bin = binOf(b, axis, centres.lo[axis], scale);
+                binBox[bin].grow(b);
+                binCount[bin] += clusters[order[i]].triangles;
+            }
+            float rightArea[kBins];
+            uint32_t rightCount[kBins];
+            HostBox run = HostBox::empty();
+            uint32_t count = 0;
+            for (int k = kBins - 1; k >= 1; --k) {
+                run.grow(binBox[k]);
+                count += binCount[k];
+                rightArea[k] = run.area();
+                rightCount[k] = count;
+            }
+            run = HostBox::empty();
+            count = 0;
+            for (int k = 1; k < kBins; ++k) {  // cut between bin k - 1 and bin k
+                run.grow(binBox[k - 1]);
+                count += binCount[k - 1];
+                if (count == 0U || rightCount[k] == 0U)
+                    continue;
+                const float cost = run.area() * static_cast<float>(count) + rightArea[k] * static_cast<float>(rightCount[k]);
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = axis;
+                    bestBin = k;
+                }
+            }
+        }
+        uint32_t middle = begin + (end - begin) / 2U;
+        if (bestAxis >= 0) {
+            const float lo = centres.lo[bestAxis];
+            const float scale = static_cast<float>(kBins) / (centres.hi[bestAxis] - lo);
+            auto split = std::stable_partition(order.begin() + begin, order.begin() + end, [&](uint32_t c) {
+                return binOf(boxes[c], bestAxis, lo, scale) < bestBin;
+            });
+            middle = static_cast<uint32_t>(split - order.begin());
+            if (middle == begin || middle == end)
+                middle = begin + (end - begin) / 2U;
+        }
+        const uint32_t self = static_cast<uint32_t>(nodes.size());
+        nodes.push_back({all, 0U, 0U, triangles});
+        const uint32_t l = build(begin, middle);
+        const uint32_t r = build(middle, end);
+        nodes[self].left = l;
+        nodes[self].right = r;
+        return self;
+    }
+
+    static int binOf(const HostBox& b, int axis, float lo, float scale) {
+        const float c = 0.5f * (b.lo[axis] + b.hi[axis]);
+        const int bin = static_cast<int>((c - lo) * scale);
+        return bin < 0 ? 0 : (bin >= kBins ? kBins - 1 : bin);
+    }
+};
+
+// Rebuilds the tree above the radix tree's subtrees of at most `limit` triangles (section 3c) and
+// renumbers the leaves; `order` comes back pointing at the new triangle order.
+rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, DeviceBuffer& right, DeviceBuffer& parent,
+                            DeviceBuffer& first, DeviceBuffer& last, DeviceBuffer& bounds, DeviceBuffer& counts,
+                            DeviceBuffer& partials, const uint32_t*& order, uint32_t* spareOrder) {
+    // about this many clusters (RT_BLAS_CLUSTERS overrides): the host's share of the build grows with it
+    uint32_t targetClusters = 8192;
+    if (const char* v = std::getenv("RT_BLAS_CLUSTERS"))
+        targetClusters = static_cast<uint32_t>(std::max(2L, std::atol(v)));
+    const uint32_t limit = std::max(4U, n / targetClusters);
+    const unsigned idBlocks = divUp(2ULL * n - 1U, 256), blocks = divUp(n, 256);
+    DeviceBuffer marks, roots, upper, upperIds, clusterRecords, upperNodes, leafPosition, leafBounds;
+    RT_TRY(marks.allocate(sizeof(uint32_t) * (static_cast<size_t>(n) + 1)));
+    RT_TRY(roots.allocate(sizeof(uint32_t) * n));
+    RT_TRY(upper.allocate(sizeof(uint32_t) * n));
+    RT_HIP(hipMemsetAsync(marks.data, 0, sizeof(uint32_t) * (static_cast<size_t>(n) + 1), stream));
+    hipLaunchKernelGGL(clusterMarkKernel, dim3(idBlocks), dim3(256), 0, stream, n, limit, parent.as<uint32_t>(),
+                       first.as<uint32_t>(), last.as<uint32_t>(), marks.as<uint32_t>(), roots.as<uint32_t>(),
+                       upper.as<uint32_t>(), counts.as<uint32_t>());
+    RT_TRY(exclusiveScanU32(marks.as<uint32_t>(), marks.as<uint32_t>(), static_cast<size_t>(n) + 1, partials.as<uint32_t>(),
+                            stream));
+    RT_TRY(exclusiveScanU32(upper.as<uint32_t>(), upper.as<uint32_t>(), n, partials.as<uint32_t>(), stream));
+    uint32_t clusterCount = 0, upperCount = 0;
+    RT_HIP(hipMemcpyAsync(&clusterCount, marks.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipMemcpyAsync(&upperCount, upper.as<uint32_t>() + (n - 1U), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    if (clusterCount < 2U)
+        return RT_SUCCESS;  // the whole tree is one cluster
+    if (upperCount + 1U != clusterCount)
+        return failInvalid("cluster cut is not a tree");
+    RT_TRY(clusterRecords.allocate(sizeof(ClusterRecord) * clusterCount));
+    RT_TRY(upperIds.allocate(sizeof(uint32_t) * upperCount));
+    hipLaunchKernelGGL(clusterGatherKernel, dim3(blocks), dim3(256), 0, stream, n, marks.as<uint32_t>(), marks.as<uint32_t>(),
+                       roots.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(),
+                       clusterRecords.as<ClusterRecord>());
+    hipLaunchKernelGGL(upperIdsKernel, dim3(blocks), dim3(256), 0, stream, n, upper.as<uint32_t>(), upperIds.as<uint32_t>());
+    std::vector<ClusterRecord> clusters(clusterCount);
+    std::vector<uint32_t> ids(upperCount);
+    RT_HIP(hipMemcpyAsync(clusters.data(), clusterRecords.data, sizeof(ClusterRecord) * clusterCount, hipMemcpyDeviceToHost,
+                          stream));
+    RT_HIP(hipMemcpyAsync(ids.data(), upperIds.data, sizeof(uint32_t) * upperCount, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    if (ids.empty() || ids[0] != 0U)
+        return failInvalid("the root is not among the upper nodes");
+
+    UpperBuilder builder(clusters);
+    builder.build(0, clusterCount);
+    if (builder.nodes.size() != upperCount)
+        return failInvalid("upper tree has the wrong size");
+    auto reference = [&](uint32_t r) {
+        return (r & UpperBuilder::kClusterBit) ? clusters[r & ~UpperBuilder::kClusterBit].node : ids[r];
+    };
+    std::vector<UpperNode> scatter(upperCount);
+    for (uint32_t k = 0; k < upperCount; ++k) {
+        const UpperBuilder::Node& node = builder.nodes[k];
+        UpperNode& out = scatter[k];
+        out.box.lo = make_float4(node.box.lo[0], node.box.lo[1], node.box.lo[2], 0.0f);
+        out.box.hi = make_float4(node.box.hi[0], node.box.hi[1], node.box.hi[2], 0.0f);
+        out.id = ids[k];  // pre-order: node 0, the root, keeps id 0
+        out.left = reference(node.left);
+        out.right = reference(node.right);
+        out.triangles = node.triangles;
+    }
+    RT_TRY(upperNodes.allocate(sizeof(UpperNode) * upperCount));
+    RT_HIP(hipMemcpyAsync(upperNodes.data, scatter.data(), sizeof(UpperNode) * upperCount, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(upperScatterKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperNodes.as<UpperNode>(),
+                       upperCount, left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), bounds.as<Box4>(),
+                       counts.as<uint32_t>());
+    // leaves in depth-first order of the new tree
+    RT_TRY(leafPosition.allocate(sizeof(uint32_t) * n));
+    RT_TRY(leafBounds.allocate(sizeof(Box4) * n));
+    hipLaunchKernelGGL(plocLeafOrderKernel, dim3(blocks), dim3(256), 0, stream, n, left.as<uint32_t>(), right.as<uint32_t>(),
+                       parent.as<uint32_t>(), counts.as<uint32_t>(), order, bounds.as<Box4>(), leafPosition.as<uint32_t>(),
+                       spareOrder, leafBounds.as<Box4>());
+    hipLaunchKernelGGL(plocRangeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                       right.as<uint32_t>(), parent.as<uint32_t>(), counts.as<uint32_t>(), first.as<uint32_t>(),
+                       last.as<uint32_t>());
+    hipLaunchKernelGGL(plocChildKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                       right.as<uint32_t>(), leafPosition.as<uint32_t>());
+    RT_HIP(hipMemcpyAsync(bounds.as<Box4>() + (n - 1U), leafBounds.data, sizeof(Box4) * n, hipMemcpyDeviceToDevice, stream));
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(stream));  // the scratch buffers of this function go out of scope
+    order = spareOrder;
+    return RT_SUCCESS;
+}
+
 rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
                     hipStream_t stream, rt_blas* blas) {
     hipEvent_t start, stop;
@@ -795,6 +1101,9 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         }
         if (!finished)
             return failInvalid("bounds pass did not finish");
+        if (refineChoice() && n >= 64U)
+            RT_TRY(refineUpperLevels(n, stream, left, right, parent, first, last, bounds, arrivals, partials, order,
+                                     idx[1 - result]));
     }
     RT_HIP(hipGetLastError());
 

@@ -329,3 +329,29 @@ def test_many_launches_in_flight_on_two_streams(engine):
         assert torch.equal(got[k][0].view(torch.int32), want[k][0].view(torch.int32)), k
         assert torch.equal(got[k][1], want[k][1]), k
         assert torch.equal(got_any[k], want_any[k]), k
+
+
+def test_surface_area_refinement_keeps_hits_and_saves_node_visits(engine, oracle, monkeypatch):
+    """The upper levels of a bottom-level tree are rebuilt with binned surface-area splits over the radix
+    tree's clusters.  Hits do not depend on the tree: the plain radix tree (RT_BLAS_REFINE=0), the default
+    and a rebuild down to clusters of four triangles all match the oracle bit for bit; on the dense mesh
+    the refined trees visit no more nodes per ray than the plain one."""
+    import torch
+    scene = workloads.dragon_cornell(triangles=120000)
+    rays = workloads.random_rays(scene, 150000, seed=17)
+    visits = {}
+    for name, env in (("plain", {"RT_BLAS_REFINE": "0"}), ("default", {}), ("deep", {"RT_BLAS_CLUSTERS": "1000000"})):
+        monkeypatch.delenv("RT_BLAS_REFINE", raising=False)
+        monkeypatch.delenv("RT_BLAS_CLUSTERS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        top, _ = check_scene(engine, oracle, scene, rays)
+        counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+        top.trace_closest(dev(rays[0]), dev(rays[1]), counters=counters)
+        c = counters.cpu().numpy()
+        visits[name] = c[1] / c[0]
+    assert visits["default"] <= visits["plain"] * 1.005 and visits["deep"] <= visits["plain"] * 1.005, visits
+    for n in (65, 200, 5000):  # sizes around the point where the rebuild starts
+        soup = workloads.triangle_soup(n, seed=n)
+        monkeypatch.setenv("RT_BLAS_CLUSTERS", "64")
+        check_scene(engine, oracle, soup, workloads.random_rays(soup, 20000, seed=n), brute=n <= 200)

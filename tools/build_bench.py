@@ -14,7 +14,8 @@ from helpers import engine_scene
 
 
 def one(name, scene, builder, rays=1 << 21):
-    os.environ["RT_BLAS_BUILDER"] = builder
+    os.environ["RT_BLAS_BUILDER"] = "ploc" if builder == "ploc" else "radix"
+    os.environ["RT_BLAS_REFINE"] = "0" if builder == "radix" else "1"  # "refined" = radix tree + surface-area upper levels
     print(f"{name}: building", flush=True)
     top, blases = engine_scene(engine, scene)
     print(f"{name}: built, generating rays", flush=True)
@@ -33,7 +34,7 @@ def one(name, scene, builder, rays=1 << 21):
         top.trace_closest(o, d, hits=hits, inst=inst)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print(f"{name:14s} {builder:6s} build {build:8.2f} ms  nodes {nodes:8d} depth {depth:3d}  nodes/ray {c[1] / c[0]:6.2f}  "
+    print(f"{name:14s} {builder:8s} build {build:8.2f} ms  nodes {nodes:8d} depth {depth:3d}  nodes/ray {c[1] / c[0]:6.2f}  "
           f"tris/ray {c[2] / c[0]:6.2f}  {rays / dt / 1e6:8.1f} Mrays/s", flush=True)
 
 
@@ -42,12 +43,13 @@ def main():
     if len(sys.argv) > 1:  # soup sizes on the command line, default builder only: the large-scene measurements
         for n in (int(a) for a in sys.argv[1:]):
             print(f"soup {n}: generating triangles", flush=True)
-            one(f"soup {n}", workloads.triangle_soup(n), "radix", rays=1 << 24)
+            for builder in ("radix", "refined"):
+                one(f"soup {n}", workloads.triangle_soup(n), builder, rays=1 << 24)
         return
     cases = [("tube 871k", workloads.dragon_cornell()), ("soup 100k", workloads.triangle_soup(100000)),
              ("soup 1M", workloads.triangle_soup(1000000)), ("spheres", workloads.sphere_field())]
     for name, scene in cases:
-        for builder in ("radix", "ploc"):
+        for builder in ("radix", "refined", "ploc"):
             one(name, scene, builder)
 
 
