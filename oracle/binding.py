@@ -41,6 +41,7 @@ def load():
         "orc_shade_hits": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
         "orc_render_sample": (None, [_vp, _vp, _u32, _u32, C.c_int]),
         "orc_trace_photons": (_u32, [_vp, _vp, _u32, _u32, _vp, _u32, C.c_int]),
+        "orc_trace_photons_indexed": (_u32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, C.c_int]),
         "orc_ray_counter": (C.c_uint64, [C.c_int]),
     }
     for name, (restype, argtypes) in sig.items():
@@ -181,6 +182,15 @@ class Scene:
         out = np.zeros((capacity, 9), dtype=np.float32)
         wanted = self.lib.orc_trace_photons(self.handle, C.byref(params), first, count, _p(out), capacity, threads)
         return out[:min(wanted, capacity)], int(wanted)
+
+    def trace_photons_indexed(self, params, first, count, capacity, threads=1):
+        """Returns (photons (n, 9) float32 in emission order, their emission indices (n,), wanted count)."""
+        out = np.zeros((capacity, 9), dtype=np.float32)
+        emission = np.zeros(capacity, dtype=np.uint32)
+        wanted = self.lib.orc_trace_photons_indexed(self.handle, C.byref(params), first, count, _p(out), _p(emission),
+                                                    capacity, threads)
+        n = min(wanted, capacity)
+        return out[:n], emission[:n], int(wanted)
 
     def close(self):
         if self.handle:

@@ -97,6 +97,9 @@ void orc_render_sample(const orc_scene* scene, const rt_launch_params* params, u
  * the tracer wanted to store. */
 uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* params, uint32_t first, uint32_t count,
                            rt_photon* out, uint32_t capacity, int threads);
+/* Same, and emission[k] = the emission index that stored photon k. */
+uint32_t orc_trace_photons_indexed(const orc_scene* scene, const rt_launch_params* params, uint32_t first,
+                                   uint32_t count, rt_photon* out, uint32_t* emission, uint32_t capacity, int threads);
 
 /* Rays traced by orc_render_sample / orc_trace_photons since the last reset
  * (for timing the oracle as the CPU baseline). */

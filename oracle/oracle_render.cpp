@@ -828,26 +828,34 @@ void orc_render_sample(const orc_scene* scene, const rt_launch_params* params, u
 // order (the canonical order; the reference appends in atomic order,
 // device.cu:716).  Returns the number of photons the tracer wanted to store;
 // at most `capacity` are written.
-uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* params, uint32_t first, uint32_t count,
-                           rt_photon* out, uint32_t capacity, int threads) {
+uint32_t orc_trace_photons_indexed(const orc_scene* scene, const rt_launch_params* params, uint32_t first,
+                                   uint32_t count, rt_photon* out, uint32_t* emission, uint32_t capacity, int threads) {
     const Ctx c{scene, params};
     const int workers = std::max(1, threads);
-    std::vector<std::vector<rt_photon>> parts(workers);
+    std::vector<std::vector<std::pair<uint32_t, rt_photon>>> parts(workers);
     parallelRange(first, first + count, workers, [&](uint32_t b, uint32_t e, int t) {
         for (uint32_t i = b; i < e; ++i) {
             rt_photon photon;
             if (tracePhoton(c, i, photon))
-                parts[t].push_back(photon);
+                parts[t].emplace_back(i, photon);
         }
     });
     uint32_t stored = 0;
     for (const auto& part : parts)
-        for (const auto& photon : part) {
-            if (stored < capacity)
-                out[stored] = photon;
+        for (const auto& entry : part) {
+            if (stored < capacity) {
+                out[stored] = entry.second;
+                if (emission)
+                    emission[stored] = entry.first;  // which emission stored this photon
+            }
             ++stored;
         }
     return stored;
+}
+
+uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* params, uint32_t first, uint32_t count,
+                           rt_photon* out, uint32_t capacity, int threads) {
+    return orc_trace_photons_indexed(scene, params, first, count, out, nullptr, capacity, threads);
 }
 
 }  // extern "C"

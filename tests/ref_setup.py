@@ -29,6 +29,32 @@ def _normalized(x, y, z):
     return np.array([x * inv, y * inv, z * inv], dtype=f32)
 
 
+TEXTURE_SLOTS = ("baseColorTexture", "metallicRoughnessTexture", "normalTexture", "emissiveTexture",
+                 "transmissionTexture", "thicknessTexture")
+
+
+def material_record(m):
+    """renderer.cpp:108-143 restated: a scene material (dict with the fields of scene.hpp:52-73) as the
+    272-byte device record; a slot without a texture is index -1, scale (1, 1), strength 1 (scene.hpp:43-50)."""
+    g = R.GpuMaterial()
+    g.baseColor = R.Float4(*[f32(v) for v in m["baseColor"]])
+    g.emissive = R.Float3(*[f32(v) for v in m["emissive"]])
+    g.attenuationColor = R.Float3(*[f32(v) for v in m["attenuationColor"]])
+    g.metallic, g.roughness, g.transmission, g.ior = m["metallic"], m["roughness"], m["transmission"], m["ior"]
+    g.thickness, g.attenuationDistance = m["thickness"], m["attenuationDistance"]
+    g.emissiveStrength, g.dispersion = m["emissiveStrength"], m["dispersion"]
+    for slot in TEXTURE_SLOTS:
+        t = m.get(slot) or {}
+        if t.get("texture", -1) >= 0 and t.get("texCoord", 0) > 1:
+            raise ValueError("Only glTF TEXCOORD_0 and TEXCOORD_1 are supported")
+        ref = getattr(g, slot)
+        ref.texture, ref.texCoord = t.get("texture", -1), t.get("texCoord", 0)
+        ref.offset = R.Float2(*t.get("offset", (0.0, 0.0)))
+        ref.scale = R.Float2(*t.get("scale", (1.0, 1.0)))
+        ref.rotation, ref.strength = t.get("rotation", 0.0), t.get("strength", 1.0)
+    return g
+
+
 class Setup:
     def __init__(self, scene, width, height, final=False, photon_budget=None):
         self.keep = []
@@ -36,7 +62,8 @@ class Setup:
         p.width, p.height = width, height
         p.maxDepth = 32 if final else 5
         # materials
-        mats = (R.GpuMaterial * len(scene["materials"]))(*[R.gpu_material(m) for m in scene["materials"]])
+        mats = (R.GpuMaterial * len(scene["materials"]))(*[material_record(m) for m in scene["materials"]])
+        self.materials = mats
         self.keep.append(mats)
         p.materials = C.addressof(mats)
         # textures
@@ -69,6 +96,7 @@ class Setup:
             if total > 0.0:
                 cdf = (cdf.astype(np.float64) / total).astype(f32)
                 self.keep += [px, cdf]
+                self.environment_cdf = cdf
                 p.environment, p.environmentCdf = px.ctypes.data, cdf.ctypes.data
                 p.environmentWidth, p.environmentHeight = w, h
                 self.environment_power = f32(total * 19.7392088 / float(w * h) * float(f32(env.get("strength", 1.0))))
