@@ -42,7 +42,7 @@ namespace rt {
 #endif
 // Triangles a lane may test per turn.
 #ifndef RT_TRACE_LEAF_STEPS
-#define RT_TRACE_LEAF_STEPS 2
+#define RT_TRACE_LEAF_STEPS 1
 #endif
 // Workgroups launched per resident workgroup slot (1 = exactly one resident set).
 // Whether a lane takes a stack entry a second time per turn, behind the leaf code.
