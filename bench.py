@@ -50,8 +50,10 @@ def parse():
     p.add_argument("--workload", default="dragon-cornell",
                    choices=["dragon-cornell", "cornell", "sphere-field", "caustic-lab"])
     p.add_argument("--photons", type=int, default=1 << 23)
-    p.add_argument("--tiles", type=int, default=3,
-                   help="concurrent parts of the frame per render() call (1 = one stream)")
+    p.add_argument("--tiles", type=int, default=1,
+                   help="regions of the frame that run side by side per render() call")
+    p.add_argument("--in-flight", type=int, default=4,
+                   help="consecutive samples of a region in flight at once (each on a stream of its own)")
     p.add_argument("--shared", action="store_true",
                    help="run the multi-GPU code path (process group, dealt-out bands, photon exchange) with however "
                         "many ranks there are, one included: a rehearsal of the N > 1 path on one GPU")
@@ -302,7 +304,7 @@ def main():
     tris_per_ray = counted[2] / counted_rays
     bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
-    renderer.set_concurrent_tiles(args.tiles)
+    renderer.set_concurrent_tiles(args.tiles, args.in_flight)
     renderer.set_measurement(time_stages=False)
     for _ in range(args.warmup):
         step()
@@ -413,6 +415,7 @@ def main():
         "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
         "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
         "concurrent_tiles": args.tiles,
+        "samples_in_flight": args.in_flight,
         "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {
             "bound": "hbm",

@@ -287,6 +287,17 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
+/* Orders the accumulation step of later rt_render_sample* calls on this state
+ * against other streams: before the running means are updated the stream
+ * waits for the HIP event `waitFor`, and behind the update it records the HIP
+ * event `record` (hipEvent_t passed as void*; either may be null, which is the
+ * default).  The running mean of a pixel must take its samples in order
+ * (src/device.cu:1043-1046), so a caller that keeps several samples of one
+ * region in flight on several streams - which hides the slow last rays of one
+ * sample's launches behind the next sample's work - chains the accumulation
+ * steps of that region with these events; everything before the accumulation
+ * of a sample is independent of other samples.  No counterpart upstream. */
+rt_status rt_wavefront_set_accumulate_events(rt_wavefront* wavefront, void* waitFor, void* record);
 /* Bucket bits (rt_photon_bucket_bitmap) of the photon grid the launch
  * parameters of later rt_render_sample calls point at, or null (the default)
  * to read every range.  The launch parameters keep the reference's layout

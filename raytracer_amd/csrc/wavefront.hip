@@ -855,6 +855,8 @@ struct rt_wavefront {
     int device = 0;
     uint32_t flags = 0;               // RT_WAVEFRONT_TIME_STAGES | RT_WAVEFRONT_COUNT_TRAVERSAL
     uint32_t shareNumerator = 1, shareDenominator = 1;  // part of the resident wave slots a ray launch takes
+    hipEvent_t accumulateAfter = nullptr;   // the accumulation of a sample waits for this event (or null)
+    hipEvent_t accumulateSignal = nullptr;  // ... and records this one behind it (or null)
     std::vector<StageTiming> timings; // pending event pairs (flag TIME_STAGES)
     std::vector<hipEvent_t> eventPool;
     rt::Buffers buffers{};
@@ -972,6 +974,14 @@ rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32
         return failInvalid("the share of a ray launch is a fraction in (0, 1]");
     w->shareNumerator = numerator;
     w->shareDenominator = denominator;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_accumulate_events(rt_wavefront* w, void* waitFor, void* record) {
+    if (!w)
+        return failInvalid("null pointer");
+    w->accumulateAfter = static_cast<hipEvent_t>(waitFor);
+    w->accumulateSignal = static_cast<hipEvent_t>(record);
     return RT_SUCCESS;
 }
 
@@ -1143,11 +1153,15 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
         StageTimer timer(w, s, 3);
         hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);
     }
+    if (w->accumulateAfter)
+        RT_HIP(hipStreamWaitEvent(s, w->accumulateAfter, 0));
     {
         StageTimer timer(w, s, 4);
         hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, map, b);
     }
     RT_HIP(hipGetLastError());
+    if (w->accumulateSignal)
+        RT_HIP(hipEventRecord(w->accumulateSignal, s));
     return RT_SUCCESS;
 }
 

@@ -137,7 +137,7 @@ class DistributedRenderer:
     """rt::Renderer sharded over the ranks of a process group.  Same calls as the single-GPU class:
     render(), linear_pixels(), samples()."""
 
-    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None):
+    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None, in_flight=4):
         import torch
         import torch.distributed as dist
         from . import renderer as R
@@ -152,7 +152,7 @@ class DistributedRenderer:
         if photon_budget is not None:
             self.renderer.set_photon_budget(*photon_budget)
         if tiles is not None:
-            self.renderer.set_concurrent_tiles(tiles)
+            self.renderer.set_concurrent_tiles(tiles, in_flight)
         self.renderer.set_manual_photon_passes(True)
         self.renderer.set_row_interleave(self.rank, self.world)
         self.exchanges = []  # per photon pass: dict(ms, photons, kept, bytes_sent, bytes_received)

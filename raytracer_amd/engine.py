@@ -75,6 +75,7 @@ SYMBOLS = {
     "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
     "rt_wavefront_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rt_wavefront_set_bucket_bitmap": (C.c_int, [_vp, _vp]),
+    "rt_wavefront_set_accumulate_events": (C.c_int, [_vp, _vp, _vp]),
     "rt_streams_run_concurrently": (C.c_int, [_vp, _u32, _vp]),
     "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
 }

@@ -430,6 +430,10 @@ int rth_renderer_set_row_interleave(rt::Renderer* r, uint32_t first, uint32_t st
 int rth_renderer_set_concurrent_tiles(rt::Renderer* r, uint32_t count) {
     return guarded([&] { r->setConcurrentTiles(count); });
 }
+int rth_renderer_set_parts_and_depth(rt::Renderer* r, uint32_t count, uint32_t samplesInFlight) {
+    return guarded([&] { r->setConcurrentTiles(count, samplesInFlight); });
+}
+uint32_t rth_renderer_samples_in_flight(rt::Renderer* r) { return r->samplesInFlight(); }
 uint32_t rth_renderer_concurrent_tiles(rt::Renderer* r) { return r->concurrentTiles(); }
 int rth_renderer_set_ray_share(rt::Renderer* r, uint32_t numerator, uint32_t denominator) {
     return guarded([&] { r->setRayShare(numerator, denominator); });

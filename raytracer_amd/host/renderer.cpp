@@ -417,13 +417,21 @@ struct Renderer::Impl {
     std::uint32_t firstBand = 0, bandStride = 1;
     bool rangeSet = false;
     std::uint32_t rangeBegin = 0, rangeEnd = 0;
+    // A frame is cut into `partCount` regions that run side by side, and `depth` samples of a region
+    // may be in flight at once: parts[(sample % depth) * partCount + region].  The accumulation steps
+    // of one region are chained by events, because a pixel's running mean takes its samples in order.
     struct Part {
         rt_wavefront* wavefront = nullptr;
         hipStream_t stream = nullptr;
+        hipEvent_t accumulated = nullptr;  // recorded behind the part's accumulation step (depth > 1)
+        bool recorded = false;
     };
     std::vector<Part> parts;
+    std::uint32_t partCount = 0, depth = 1;
     std::uint32_t measurementFlags = 0;
-    static constexpr std::uint32_t kDefaultParts = 3;
+    // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
+    // launches leave the GPU half idle in their tails; four of them side by side fill it)
+    static constexpr std::uint32_t kDefaultParts = 1, kDefaultDepth = 4;
 
     ~Impl() {
         (void)hipDeviceSynchronize();
@@ -463,7 +471,7 @@ struct Renderer::Impl {
         launch.sceneRadius = sphere.radius;
         setPhotonSizes(1U << 24U, 1U << 23U, 1U << 22U);  // renderer.cpp:533-535
         allocateFrame();
-        createParts(kDefaultParts);
+        createParts(kDefaultParts, kDefaultDepth);
         applyProfile(profile);
         applyCamera(scene.cameras.front());
         restart();
@@ -653,6 +661,9 @@ struct Renderer::Impl {
     }
 
     void restart() {  // renderer.cpp:716-728
+        hipOk(hipDeviceSynchronize());  // samples may still be in flight on the parts' streams
+        for (Part& part : parts)
+            part.recorded = false;
         for (std::size_t offset : aovOffset)
             hipOk(hipMemset(framePool.at<void>(offset), 0, aovBytes));
         launch.photonPass = 0;
@@ -733,24 +744,40 @@ struct Renderer::Impl {
         // The parts run on their own streams, so the slow rays that end one part's ray launch overlap
         // with the other parts' work instead of idling the GPU.  The streams are ordinary (blocking)
         // ones: work on the default stream before and after still orders against them.
-        const std::uint32_t count = static_cast<std::uint32_t>(parts.size());
+        const std::uint32_t count = partCount;
+        const std::uint32_t set = sample % depth, before = (sample + depth - 1U) % depth;
+        auto partOf = [&](std::uint32_t k) -> Part& {
+            Part& part = parts[set * count + k];
+            if (depth > 1U) {
+                // this region's previous sample was accumulated by the part of the set before this one
+                Part& previous = parts[before * count + k];
+                engineOk(rt_wavefront_set_accumulate_events(part.wavefront, previous.recorded ? previous.accumulated : nullptr,
+                                                            part.accumulated),
+                         "rt_wavefront_set_accumulate_events");
+                part.recorded = true;
+            }
+            return part;
+        };
         if (rangeSet) {
             const std::uint64_t pixels = rangeEnd - rangeBegin;
             for (std::uint32_t k = 0; k < count; ++k) {
                 const auto begin = rangeBegin + static_cast<std::uint32_t>(pixels * k / count);
                 const auto end = rangeBegin + static_cast<std::uint32_t>(pixels * (k + 1) / count);
-                engineOk(rt_render_sample_seeded(parts[k].wavefront, &launch, begin, end, seed, parts[k].stream),
-                         "rt_render_sample");
+                Part& part = partOf(k);
+                engineOk(rt_render_sample_seeded(part.wavefront, &launch, begin, end, seed, part.stream), "rt_render_sample");
             }
         } else {
             const std::uint32_t bands = (height + kBandRows - 1U) / kBandRows;
             const std::uint64_t mine = firstBand < bands ? (bands - 1U - firstBand) / bandStride + 1U : 0U;
             for (std::uint32_t k = 0; k < count; ++k) {
                 const auto from = static_cast<std::uint32_t>(mine * k / count), to = static_cast<std::uint32_t>(mine * (k + 1) / count);
+                Part& part = partOf(k);
                 if (to > from)
-                    engineOk(rt_render_sample_bands(parts[k].wavefront, &launch, firstBand + from * bandStride, bandStride,
-                                                    to - from, seed, parts[k].stream),
+                    engineOk(rt_render_sample_bands(part.wavefront, &launch, firstBand + from * bandStride, bandStride,
+                                                    to - from, seed, part.stream),
                              "rt_render_sample_bands");
+                else
+                    part.recorded = false;  // nothing was enqueued, so nothing records the event
             }
         }
         ++sample;
@@ -764,30 +791,36 @@ struct Renderer::Impl {
                 rt_wavefront_destroy(part.wavefront);
             if (part.stream)
                 (void)hipStreamDestroy(part.stream);
+            if (part.accumulated)
+                (void)hipEventDestroy(part.accumulated);
         }
         parts.clear();
     }
 
-    void createParts(std::uint32_t count) {
+    void createParts(std::uint32_t count, std::uint32_t samplesInFlight = 1) {
         hipOk(hipDeviceSynchronize());
         destroyParts();
         count = std::clamp<std::uint32_t>(count, 1U, 8U);
+        depth = std::clamp<std::uint32_t>(samplesInFlight, 1U, 8U);
+        partCount = count;
         // room for the larger of an even share of the pixels and an even share of the bands
         const std::uint64_t pixels = static_cast<std::uint64_t>(width) * height;
         const std::uint64_t bands = (height + kBandRows - 1U) / kBandRows;
         const std::uint64_t capacity =
             std::min(pixels, std::max((pixels + count - 1U) / count, (bands + count - 1U) / count * kBandRows * width));
-        parts.resize(count);
-        if (count > 1)
+        parts.resize(static_cast<std::size_t>(count) * depth);
+        if (parts.size() > 1)
             pickStreams();
         for (Part& part : parts) {
             engineOk(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &part.wavefront), "rt_wavefront_create");
             engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
-            // a single part stays on the default stream; the parts of a split frame take half the wave
+            // a single part stays on the default stream; parts that run side by side take half the wave
             // slots per ray launch: two of them then trace side by side, each filling the slots the
             // other's last rays leave idle
-            if (count > 1)
+            if (parts.size() > 1)
                 engineOk(rt_wavefront_set_ray_share(part.wavefront, 1, 2), "rt_wavefront_set_ray_share");
+            if (depth > 1)
+                hipOk(hipEventCreateWithFlags(&part.accumulated, hipEventDisableTiming));
         }
         shareBucketBits();
     }
@@ -948,14 +981,18 @@ void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
     }
 }
 
-void Renderer::setConcurrentTiles(std::uint32_t count) { impl_->createParts(count); }
+void Renderer::setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight) {
+    impl_->createParts(count, samplesInFlight);
+    impl_->restart();
+}
 
 void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
     for (auto& part : impl_->parts)
         engineOk(rt_wavefront_set_ray_share(part.wavefront, numerator, denominator), "rt_wavefront_set_ray_share");
 }
 
-std::uint32_t Renderer::concurrentTiles() const { return static_cast<std::uint32_t>(impl_->parts.size()); }
+std::uint32_t Renderer::concurrentTiles() const { return impl_->partCount; }
+std::uint32_t Renderer::samplesInFlight() const { return impl_->depth; }
 void Renderer::synchronize() const { hipOk(hipDeviceSynchronize()); }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }
 float Renderer::causticRadius() const { return impl_->gatherRadius; }

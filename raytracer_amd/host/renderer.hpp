@@ -54,10 +54,16 @@ public:
     // frame in turn, which spreads rows that are dear to trace over all of them.  Replaces a pixel
     // range; (0, 1), the default, is the whole frame.
     void setRowInterleave(std::uint32_t first, std::uint32_t stride);
-    // render() cuts its pixel range into `count` parts (1..8, default 3) that run
+    // render() cuts its pixel range into `count` parts (1..8, default 1) that run
     // concurrently on streams of their own; the image does not depend on it.
     // With more than one part the stage timings of the parts overlap in time.
-    void setConcurrentTiles(std::uint32_t count);
+    // samplesInFlight > 1 (at most 8) lets that many consecutive samples of a region run at once, each
+    // on a stream of its own, their accumulation steps chained in sample order: for small frames or
+    // small shares of one, where a single sample's launches cannot fill the GPU.  Restarts the
+    // accumulation.
+    // The default is one region with four samples in flight.
+    void setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight = 1);
+    std::uint32_t samplesInFlight() const;
     // Share of the GPU's wave slots a ray launch of one part takes (setConcurrentTiles
     // resets it: 1/2 for a split frame, 1/1 otherwise).
     void setRayShare(std::uint32_t numerator, std::uint32_t denominator);

@@ -115,6 +115,8 @@ _SIG = {
     "rth_renderer_set_row_interleave": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_concurrent_tiles": (C.c_int, [_vp, _u32]),
     "rth_renderer_concurrent_tiles": (_u32, [_vp]),
+    "rth_renderer_set_parts_and_depth": (C.c_int, [_vp, _u32, _u32]),
+    "rth_renderer_samples_in_flight": (_u32, [_vp]),
     "rth_renderer_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
@@ -415,8 +417,13 @@ class Renderer:
         """render() covers every stride-th band of eight pixel rows from band `first` on (replaces a pixel range)."""
         _check(load().rth_renderer_set_row_interleave(self.handle, first, stride))
 
-    def set_concurrent_tiles(self, count):
-        _check(load().rth_renderer_set_concurrent_tiles(self.handle, count))
+    def set_concurrent_tiles(self, count, samples_in_flight=1):
+        """render() cuts its pixels into `count` regions that run side by side; with samples_in_flight > 1
+        that many consecutive samples of a region may run at once.  Restarts the accumulation."""
+        _check(load().rth_renderer_set_parts_and_depth(self.handle, count, samples_in_flight))
+
+    def samples_in_flight(self):
+        return int(load().rth_renderer_samples_in_flight(self.handle))
 
     def set_ray_share(self, numerator, denominator):
         """Share of the GPU's wave slots a ray launch of one part of the frame takes (reset by set_concurrent_tiles)."""

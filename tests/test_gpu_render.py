@@ -460,16 +460,19 @@ def test_render_into_and_copy_to_caller_owned_device_buffers(R):
 
 
 def test_concurrent_tiles_do_not_change_the_image(R):
-    """render() cut into 1, 2 or 5 concurrent parts (own streams, own wavefront state) gives bit-identical
+    """render() cut into 1, 2 or 5 concurrent parts (own streams, own wavefront state), with one to eight
+    samples of a part in flight (their accumulation steps chained by events), gives bit-identical
     buffers; 72 rows exercise full 8-row bands, leftover rows and parts that start inside a band."""
     scene = workloads.cornell_box(light="panel")
     w, h = 64, 72
     images = []
-    for tiles in (1, 2, 5):
+    default = R.Renderer(scene, w, h)
+    assert (default.concurrent_tiles(), default.samples_in_flight()) == (1, 4)
+    for tiles, depth in ((1, 1), (2, 1), (5, 1), (1, 4), (2, 3), (1, 8)):
         r = R.Renderer(scene, w, h)
-        r.set_concurrent_tiles(tiles)
-        assert r.concurrent_tiles() == tiles
-        for _ in range(3):
+        r.set_concurrent_tiles(tiles, depth)
+        assert r.concurrent_tiles() == tiles and r.samples_in_flight() == depth
+        for _ in range(7):
             r.render()
         images.append((r.linear_pixels().copy(), r.pixels().copy(), r.statistics()))
     for pixels, bytes8, stats in images[1:]:
@@ -480,11 +483,11 @@ def test_concurrent_tiles_do_not_change_the_image(R):
     scene = workloads.caustic_lab()
     w, h = 64, 40
     images = []
-    for tiles in (1, 3, 4):
+    for tiles, depth in ((1, 1), (3, 1), (4, 1), (1, 4), (1, 3), (2, 2)):
         r = R.Renderer(scene, w, h, 1)
         r.set_photon_budget(1 << 19, 1 << 18, 1 << 14)
-        r.set_concurrent_tiles(tiles)
-        for _ in range(5):           # photon passes before samples 0 and 4
+        r.set_concurrent_tiles(tiles, depth)
+        for _ in range(6):           # photon passes before samples 0 and 4
             r.render()
         r.synchronize()
         images.append((np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]),
