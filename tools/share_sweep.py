@@ -7,8 +7,8 @@ from raytracer_amd import renderer as R, workloads
 R.load()
 scene = workloads.dragon_cornell()
 r = R.Renderer(scene, 1920, 1080, 0)
-for share in (1, 2, 4, 8):
-    for tiles, depth in ((1, 1), (3, 1), (1, 2), (1, 3), (2, 2), (1, 4), (3, 2)):
+for share in (1, 4, 8):
+    for tiles, depth in ((1, 4), (1, 6), (1, 8), (1, 12)):
         r.set_concurrent_tiles(tiles, depth)
         r.set_row_interleave(0, share)
         for _ in range(8):
