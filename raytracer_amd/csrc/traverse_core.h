@@ -397,8 +397,45 @@ struct Traversal {
         if (COUNT)
             ++counters.nodes;
         GlobalUint4 np = globalView(nodes + node);
-        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        const uint32_t imask = n0.w >> 24;
+        const uint4 n0 = np[0], n2 = np[2], n3 = np[3], n4 = np[4];
+        uint4 n1 = np[1];
+        uint32_t imask = n0.w >> 24;
+        // A ray parallel to an axis (a direction component of exactly zero) is unconstrained on that axis
+        // below: its plane distances are 0 * inf or inf - inf, the NaN that fmaxf / fminf drop.  That is
+        // safe but lets the ray into every child along the axis - a hundred times the visits of its
+        // neighbours, alone in its wave.  Such a ray can only enter a child whose slab holds its origin,
+        // which is tested on the planes themselves.  The difference below is rounded, but towards the
+        // plane it is compared with, never across it: a child is only dropped when the origin is outside.
+        if ((cur.dx * cur.dy) * cur.dz == 0.0f) {
+            auto outsideSlab = [&](float direction, float origin, uint32_t corner, uint32_t exponent, uint32_t lo0,
+                                   uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint32_t {
+                if (direction != 0.0f)
+                    return 0U;
+                const float scale = __uint_as_float((exponent & 0xffU) << 23);
+                const float offset = __uint_as_float(corner) - origin;
+                uint32_t outside = 0U;
+#pragma unroll
+                for (int i = 0; i < kWide; ++i) {
+                    const int sh = 8 * (i & 3);
+                    const float qlo = static_cast<float>(((i < 4 ? lo0 : lo1) >> sh) & 0xffU);
+                    const float qhi = static_cast<float>(((i < 4 ? hi0 : hi1) >> sh) & 0xffU);
+                    if (fmaf(qlo, scale, offset) > 0.0f || fmaf(qhi, scale, offset) < 0.0f)
+                        outside |= 1U << i;
+                }
+                return outside;
+            };
+            const uint32_t outside = outsideSlab(cur.dx, cur.ox, n0.x, n0.w, n2.x, n2.y, n3.z, n3.w) |
+                                     outsideSlab(cur.dy, cur.oy, n0.y, n0.w >> 8, n2.z, n2.w, n4.x, n4.y) |
+                                     outsideSlab(cur.dz, cur.oz, n0.z, n0.w >> 16, n3.x, n3.y, n4.z, n4.w);
+            // a child that is dropped is struck from the node: no inner bit, no triangle count
+            auto bytesOf = [](uint32_t four) -> uint32_t {
+                return ((four & 1U) ? 0xffU : 0U) | ((four & 2U) ? 0xff00U : 0U) | ((four & 4U) ? 0xff0000U : 0U) |
+                       ((four & 8U) ? 0xff000000U : 0U);
+            };
+            imask &= ~outside;
+            n1.z &= ~bytesOf(outside & 15U);
+            n1.w &= ~bytesOf(outside >> 4);
+        }
         // child plane distance = q * a + b per axis; the near planes are shrunk
         // and the far planes grown by 2^-20 relative, so rounding never rejects
         // a box whose triangle the intersection test accepts

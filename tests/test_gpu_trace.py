@@ -355,3 +355,46 @@ def test_surface_area_refinement_keeps_hits_and_saves_node_visits(engine, oracle
         soup = workloads.triangle_soup(n, seed=n)
         monkeypatch.setenv("RT_BLAS_CLUSTERS", "64")
         check_scene(engine, oracle, soup, workloads.random_rays(soup, 20000, seed=n), brute=n <= 200)
+
+
+def test_axis_parallel_rays_stay_cheap(engine, oracle):
+    """Rays with one or two direction components of exactly zero (probe rays along the axes, rays inside an
+    axis plane - also what a normal generator yields now and then, a few in 2^24) on a 200 k soup: the
+    same bits as the oracle, origins on the coordinates of triangle corners included, and about as many
+    node visits as their oblique neighbours, where a slab test that leaves the parallel axis open visits
+    a hundred times as many."""
+    import torch
+    scene = workloads.triangle_soup(200000, seed=11)
+    rng = np.random.default_rng(12)
+    n = 60000
+    o, d = workloads.random_rays(scene, n, seed=13)
+    oblique = (o.copy(), d.copy())
+    kind = rng.integers(0, 3, n)
+    axis = rng.integers(0, 3, n)
+    for k in range(3):
+        one = (kind == 0) & (axis == k)           # one component zero: the ray lies in a plane
+        d[one, k] = 0.0
+        two = (kind == 1) & (axis == k)           # two components zero: along axis k
+        d[two, (k + 1) % 3] = 0.0
+        d[two, (k + 2) % 3] = 0.0
+    d[kind == 2, 1] = -0.0                        # minus zero counts as zero
+    d[:, :3] /= np.linalg.norm(d[:, :3], axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    # a third of the origins sit exactly on corner coordinates of the mesh along the parallel axis
+    corners = scene["geometries"][0]["vertices"][:, :3]
+    picks = rng.integers(0, len(corners), n)
+    snap = rng.random(n) < 0.33
+    for k in range(3):
+        rows = snap & (d[:, k] == 0.0)
+        o[rows, k] = corners[picks[rows], k]
+    assert (d[:, :3] == 0).any(axis=1).mean() > 0.9
+    top, _ = check_scene(engine, oracle, scene, (o, d))
+
+    def visits(rays):
+        c = torch.zeros(4, dtype=torch.int64, device="cuda")
+        top.trace_closest(dev(rays[0]), dev(rays[1]), counters=c)
+        c = c.cpu().numpy()
+        return c[1] / c[0]
+    parallel, ordinary = visits((o, d)), visits(oblique)
+    print(f"nodes per ray: axis-parallel {parallel:.1f}, oblique {ordinary:.1f}")
+    assert parallel < 1.5 * ordinary
