@@ -304,6 +304,43 @@ rt_status rt_wavefront_set_accumulate_events(rt_wavefront* wavefront, void* wait
  * (gpu_shared.hpp:95-145), which has no room for the pointer.  The caller
  * keeps the bits in step with the grid. */
 rt_status rt_wavefront_set_bucket_bitmap(rt_wavefront* wavefront, const uint32_t* bitmap);
+/* ---- light index ------------------------------------------------------------
+ * The reference picks a light by subtracting the weights of the light list
+ * from a random target until the remainder is no longer positive
+ * (src/device.cu:433-447) and finds the light of an emissive triangle a path
+ * hit by comparing every light with the hit (src/device.cu:607-621): a walk
+ * over the whole list per shaded point.  The index holds, per light, the
+ * largest float target for which that walk has stopped at the light or before
+ * it - found by running the walk's rounded subtractions backwards, so a binary
+ * search over these thresholds returns the walk's light for every target, bit
+ * for bit - and a hash table from (instance, primitive) to the first light of
+ * that triangle.  Optional: without it the kernels walk the list.  Lists of
+ * more than 2^20 lights, or with a weight that is negative or not finite, get
+ * the table only (the thresholds take lightCount^2 / 2 steps to build: 35 ms
+ * for 2^18 lights on an MI355X).
+ * rt_light_index_bytes: size of the caller-owned device memory an index for
+ * lightCount lights takes (8-byte aligned). */
+rt_status rt_light_index_bytes(uint32_t lightCount, size_t* bytes);
+/* Builds the index of `lights` (device, the array rt_launch_params.lights
+ * points at) into `index`.  Waits for the stream once (the weights are
+ * checked first). */
+rt_status rt_light_index_build(const rt_gpu_light* lights, uint32_t lightCount, void* index, size_t indexBytes,
+                               void* stream);
+/* The index of the light list the launch parameters of later rt_render_sample*
+ * and rt_trace_photons calls on this state point at, or null (the default) to
+ * walk the list.  The launch parameters keep the reference's layout
+ * (gpu_shared.hpp:95-145), which has no room for the pointer. */
+rt_status rt_wavefront_set_light_index(rt_wavefront* wavefront, const void* index, uint32_t lightCount);
+/* The two questions of the reference's light code for n inputs at once (all
+ * arrays device): chosen[i] = the light src/device.cu:433-447 selects for the
+ * uniform number uniform[i] (target = uniform[i] * lightWeight); found[i] = the
+ * light src/device.cu:607-621 finds for the triangle (instance[i],
+ * primitive[i]), or 0xffffffff.  Through `index`, or by the walks themselves
+ * when `index` is null.  Either pair of arrays may be null. */
+rt_status rt_light_query(const rt_gpu_light* lights, uint32_t lightCount, float lightWeight, const void* index,
+                         const float* uniform, const uint32_t* instance, const uint32_t* primitive, uint32_t n,
+                         uint32_t* chosen, uint32_t* found, void* stream);
+
 /* Whether kernels put on these HIP streams (at most 16) really run side by
  * side: a process has a limited number of hardware queues, streams beyond
  * that number share one, and work on two streams of one queue runs in turn.

@@ -43,6 +43,7 @@ def load():
         "orc_trace_photons": (_u32, [_vp, _vp, _u32, _u32, _vp, _u32, C.c_int]),
         "orc_trace_photons_indexed": (_u32, [_vp, _vp, _u32, _u32, _vp, _vp, _u32, C.c_int]),
         "orc_ray_counter": (C.c_uint64, [C.c_int]),
+        "orc_light_walks": (None, [_vp, _u32, _f32, _vp, _vp, _vp, _u32, _vp, _vp, C.c_int]),
     }
     for name, (restype, argtypes) in sig.items():
         fn = getattr(lib, name)
@@ -109,6 +110,22 @@ def random_stream(state, count):
     lib = load()
     vals = np.array([lib.orc_random(C.byref(s)) for _ in range(count)], dtype=np.float32)
     return vals, s.value
+
+
+def light_walks(lights, light_weight, uniform=None, instance=None, primitive=None, threads=1):
+    """The reference's walks over a light list (device.cu:433-447, 607-621) for arrays of inputs.
+    lights: uint8 array of n * 92 bytes (rt_gpu_light records).  Returns (chosen, found) uint32 arrays
+    (None where the inputs were not given)."""
+    lights = np.ascontiguousarray(lights, dtype=np.uint8)
+    count = lights.size // 92
+    n = len(uniform) if uniform is not None else len(instance)
+    chosen = np.zeros(n, dtype=np.uint32) if uniform is not None else None
+    found = np.zeros(n, dtype=np.uint32) if instance is not None else None
+    keep = [np.ascontiguousarray(a, dtype=t) if a is not None else None
+            for a, t in ((uniform, np.float32), (instance, np.uint32), (primitive, np.uint32))]
+    load().orc_light_walks(_p(lights), count, light_weight, *[_p(a) if a is not None else None for a in keep], n,
+                           _p(chosen) if chosen is not None else None, _p(found) if found is not None else None, threads)
+    return chosen, found
 
 
 def ray_counter(reset=False):

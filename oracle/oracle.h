@@ -101,6 +101,15 @@ uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* param
 uint32_t orc_trace_photons_indexed(const orc_scene* scene, const rt_launch_params* params, uint32_t first,
                                    uint32_t count, rt_photon* out, uint32_t* emission, uint32_t capacity, int threads);
 
+/* The two walks of the reference's light code over `lights` for n inputs:
+ * chosen[i] = the light device.cu:433-447 selects for the uniform number
+ * uniform[i]; found[i] = the light device.cu:607-621 finds for the triangle
+ * (instance[i], primitive[i]), 0xffffffff when there is none.  Either pair of
+ * arrays may be null. */
+void orc_light_walks(const rt_gpu_light* lights, uint32_t lightCount, float lightWeight, const float* uniform,
+                     const uint32_t* instance, const uint32_t* primitive, uint32_t n, uint32_t* chosen, uint32_t* found,
+                     int threads);
+
 /* Rays traced by orc_render_sample / orc_trace_photons since the last reset
  * (for timing the oracle as the CPU baseline). */
 uint64_t orc_ray_counter(int reset);

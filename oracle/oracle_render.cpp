@@ -858,4 +858,44 @@ uint32_t orc_trace_photons(const orc_scene* scene, const rt_launch_params* param
     return orc_trace_photons_indexed(scene, params, first, count, out, nullptr, capacity, threads);
 }
 
+void orc_light_walks(const rt_gpu_light* lights, uint32_t lightCount, float lightWeight, const float* uniform,
+                     const uint32_t* instance, const uint32_t* primitive, uint32_t n, uint32_t* chosen, uint32_t* found,
+                     int threads) {
+    if (lightCount == 0U)
+        return;
+    auto work = [&](uint32_t begin, uint32_t end) {
+        for (uint32_t i = begin; i < end; ++i) {
+            if (uniform && chosen) {  // device.cu:433-447
+                float target = uniform[i] * lightWeight;
+                uint32_t selected = lightCount - 1U;
+                for (uint32_t index = 0; index < lightCount; ++index) {
+                    target -= lights[index].weight;
+                    if (target <= 0.0f) {
+                        selected = index;
+                        break;
+                    }
+                }
+                chosen[i] = selected;
+            }
+            if (instance && primitive && found) {  // device.cu:607-621
+                uint32_t light = 0xffffffffU;
+                for (uint32_t index = 0; index < lightCount; ++index)
+                    if (lights[index].type == 3U && lights[index].instance == instance[i] &&
+                        lights[index].primitive == primitive[i]) {
+                        light = index;
+                        break;
+                    }
+                found[i] = light;
+            }
+        }
+    };
+    const uint32_t workers = static_cast<uint32_t>(threads < 1 ? 1 : threads);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < workers; ++t)
+        pool.emplace_back(work, static_cast<uint32_t>(static_cast<uint64_t>(n) * t / workers),
+                          static_cast<uint32_t>(static_cast<uint64_t>(n) * (t + 1U) / workers));
+    for (std::thread& t : pool)
+        t.join();
+}
+
 }  // extern "C"

@@ -6,6 +6,7 @@
 #pragma once
 
 #include "bvh.h"
+#include "light_index.h"
 
 namespace rt {
 
@@ -286,17 +287,24 @@ __device__ inline float specularChoice(const rt_gpu_material& m, V3 view, V3 nor
     return fminf(fmaxf(maximum(reflectance), 0.05f), 0.95f);
 }
 
-// device.cu:433-447: linear walk over the light weights
-__device__ inline const rt_gpu_light* pickLight(const rt_launch_params& p, uint32_t& rng, float& probability) {
+// device.cu:433-447: the light at which the running remainder of the weights stops being positive;
+// by the thresholds of the light index where there is one, else by the walk itself - the same light
+// for the same random number either way.
+__device__ inline const rt_gpu_light* pickLight(const rt_launch_params& p, const LightIndex& lightIndex, uint32_t& rng,
+                                                float& probability) {
     if (p.lightCount == 0U || p.lightWeight <= 0.0f)
         return nullptr;
     float target = random01(rng) * p.lightWeight;
     const rt_gpu_light* selected = &p.lights[p.lightCount - 1U];
-    for (uint32_t index = 0; index < p.lightCount; ++index) {
-        selected = &p.lights[index];
-        target -= selected->weight;
-        if (target <= 0.0f)
-            break;
+    if (lightIndex.thresholds && lightIndex.count == p.lightCount && p.lightCount > kLightWalkLimit) {
+        selected = &p.lights[lightByThreshold(lightIndex, target)];
+    } else {
+        for (uint32_t index = 0; index < p.lightCount; ++index) {
+            selected = &p.lights[index];
+            target -= selected->weight;
+            if (target <= 0.0f)
+                break;
+        }
     }
     probability = selected->weight / p.lightWeight;
     return selected;
@@ -346,10 +354,10 @@ struct LightDraw {  // device.cu:415-425
 };
 
 // device.cu:480-546
-__device__ inline LightDraw drawLight(const rt_launch_params& p, V3 position, uint32_t& rng) {
+__device__ inline LightDraw drawLight(const rt_launch_params& p, const LightIndex& lightIndex, V3 position, uint32_t& rng) {
     LightDraw sample;
     float choice = 0.0f;
-    const rt_gpu_light* selected = pickLight(p, rng, choice);
+    const rt_gpu_light* selected = pickLight(p, lightIndex, rng, choice);
     if (!selected)
         return sample;
     const rt_gpu_light light = *selected;
@@ -427,10 +435,19 @@ __device__ inline float environmentDensity(const rt_launch_params& p, V3 directi
 }
 
 // device.cu:607-621: density of having sampled this emissive triangle from `origin`
-__device__ inline float emissiveDensity(const rt_launch_params& p, V3 origin, const rt_hit& hit) {
+__device__ inline float emissiveDensity(const rt_launch_params& p, const LightIndex& lightIndex, V3 origin, const rt_hit& hit) {
     const V3 offset = v3(hit.position) - origin;
     const float distanceSquared = dot(offset, offset);
     const V3 direction = offset / sqrtf(distanceSquared);
+    if (lightIndex.keys && lightIndex.count == p.lightCount && p.lightCount > kLightWalkLimit) {
+        // the first light of this triangle in table order, which is the one the walk below returns at
+        const uint32_t index = lightOfTriangle(lightIndex, hit.instance, hit.primitive);
+        if (index >= p.lightCount)
+            return 0.0f;
+        const rt_gpu_light& light = p.lights[index];
+        const float cosine = fabsf(dot(v3(light.normal), -direction));
+        return light.weight / p.lightWeight * distanceSquared / fmaxf(light.area * cosine, 1e-8f);
+    }
     for (uint32_t index = 0; index < p.lightCount; ++index) {
         const rt_gpu_light& light = p.lights[index];
         if (light.type != 3U || light.instance != hit.instance || light.primitive != hit.primitive)

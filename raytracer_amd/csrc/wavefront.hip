@@ -58,6 +58,7 @@ struct Buffers {
     unsigned long long* stats;   // [0] extend rays, [1] shadow rays, [2] gathers, [3] photons visited by gathers,
                                  // [4] nodes, [5] triangles, [6] instances visited by counted extend launches
     const uint32_t* bucketBits;  // one bit per bucket of the photon grid, or null
+    LightIndex lightIndex;       // thresholds and triangle table of the light list, or empty
     rt_photon* photonTemp;       // photon pass: one slot per emission of the batch
     uint32_t* photonFlags;
 };
@@ -367,7 +368,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         if (medium >= 0)
             throughput = throughput * mediumAbsorption(p.materials[medium], hit.distance);
         // device.cu:943-947
-        const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, lastOrigin, hit);
+        const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, b.lightIndex, lastOrigin, hit);
         const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
         V3 radiance = rgb(b.sample[lobe][path]);
         radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
@@ -377,7 +378,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         // light is seen
         const float diffuseWeight = (1.0f - m.metallic) * (1.0f - m.transmission);
         if (diffuseWeight > 0.0f) {
-            const LightDraw light = drawLight(p, v3(hit.position), rng);
+            const LightDraw light = drawLight(p, b.lightIndex, v3(hit.position), rng);
             const float cosine = dot(normal, light.direction);
             if (light.valid && cosine > 0.0f) {
                 const V3 reflectance = schlickFresnel(normalReflectance(m), fmaxf(dot(view, normal), 0.0f));
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
         b.photonFlags[i] = 0;
         rng = seeded(first + i, p.photonPass);
         float choice = 0.0f;
-        const rt_gpu_light* selected = pickLight(p, rng, choice);
+        const rt_gpu_light* selected = pickLight(p, b.lightIndex, rng, choice);
         if (selected) {
             const rt_gpu_light light = *selected;
             const float normalization = 1.0f / (static_cast<float>(p.photonEmissions) * choice);
@@ -989,6 +990,20 @@ rt_status rt_wavefront_set_bucket_bitmap(rt_wavefront* w, const uint32_t* bitmap
     if (!w)
         return failInvalid("null pointer");
     w->buffers.bucketBits = bitmap;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_light_index(rt_wavefront* w, const void* index, uint32_t lightCount) {
+    if (!w)
+        return failInvalid("null pointer");
+    w->buffers.lightIndex = rt::LightIndex{};
+    if (!index || lightCount == 0)
+        return RT_SUCCESS;
+    uint32_t header[4] = {};
+    RT_HIP(hipMemcpy(header, index, sizeof(header), hipMemcpyDeviceToHost));
+    if (header[0] != lightCount || header[1] != rt::lightTableCapacity(lightCount))
+        return failInvalid("the light index was built for another light count");
+    w->buffers.lightIndex = rt::lightIndexView(index, lightCount, header[2] != 0U);
     return RT_SUCCESS;
 }
 

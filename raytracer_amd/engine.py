@@ -75,6 +75,10 @@ SYMBOLS = {
     "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
     "rt_wavefront_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rt_wavefront_set_bucket_bitmap": (C.c_int, [_vp, _vp]),
+    "rt_light_index_bytes": (C.c_int, [_u32, C.POINTER(C.c_size_t)]),
+    "rt_light_index_build": (C.c_int, [_vp, _u32, _vp, C.c_size_t, _vp]),
+    "rt_wavefront_set_light_index": (C.c_int, [_vp, _vp, _u32]),
+    "rt_light_query": (C.c_int, [_vp, _u32, C.c_float, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rt_wavefront_set_accumulate_events": (C.c_int, [_vp, _vp, _vp]),
     "rt_streams_run_concurrently": (C.c_int, [_vp, _u32, _vp]),
     "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
@@ -328,3 +332,51 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+LIGHT_BYTES = 92  # sizeof(rt_gpu_light)
+
+
+class LightIndex:
+    """Thresholds and triangle table of a light list (rt_light_index_build): selects the light the
+    reference's walk over the list selects (device.cu:433-447, 607-621) without the walk."""
+
+    def __init__(self, lights, stream=None):
+        """lights: device uint8 tensor of n * 92 bytes, the rt_gpu_light records."""
+        import torch
+        assert lights.is_cuda and lights.dtype == torch.uint8 and lights.is_contiguous()
+        assert lights.numel() % LIGHT_BYTES == 0
+        self.lights = lights
+        self.count = lights.numel() // LIGHT_BYTES
+        size = C.c_size_t()
+        check(load().rt_light_index_bytes(self.count, C.byref(size)))
+        self.memory = torch.empty((size.value + 7) // 8, dtype=torch.int64, device=lights.device)
+        check(load().rt_light_index_build(_ptr(lights), self.count, _ptr(self.memory), size.value, _stream(stream)))
+
+    def words(self):
+        """The index as 32-bit words (header, thresholds, weights, table)."""
+        import torch
+        return self.memory.view(torch.int32)
+
+    def thresholds(self):
+        import torch
+        w = self.words()
+        assert int(w[2]) == 1, "this light list has no thresholds"
+        return w[4:4 + self.count].view(torch.float32)
+
+
+def light_query(lights, light_weight, index=None, uniform=None, instance=None, primitive=None, stream=None):
+    """rt_light_query: (chosen, found) int32 tensors (None where the inputs were not given); through
+    `index` (a LightIndex) or by the walks themselves."""
+    import torch
+    count = lights.numel() // LIGHT_BYTES
+    n = uniform.numel() if uniform is not None else instance.numel()
+    chosen = torch.empty(n, dtype=torch.int32, device=lights.device) if uniform is not None else None
+    found = torch.empty(n, dtype=torch.int32, device=lights.device) if instance is not None else None
+    check(load().rt_light_query(_ptr(lights), count, float(light_weight), _ptr(index.memory) if index else None,
+                                _ptr(uniform) if uniform is not None else None,
+                                _ptr(instance) if instance is not None else None,
+                                _ptr(primitive) if primitive is not None else None, n,
+                                _ptr(chosen) if chosen is not None else None,
+                                _ptr(found) if found is not None else None, _stream(stream)))
+    return chosen, found

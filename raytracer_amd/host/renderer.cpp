@@ -26,6 +26,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -386,6 +387,8 @@ struct Renderer::Impl {
         rt_blas* blas = nullptr;
     };
     DevicePool scenePool;
+    std::size_t lightIndexAt = 0;
+    void* lightIndex = nullptr;  // in the scene pool: thresholds and triangle table of the light list
     std::vector<Mesh> meshes;
     rt_scene* tree = nullptr;
 
@@ -504,6 +507,10 @@ struct Renderer::Impl {
 
         const LightTable lights = lightTable(scene, sky.power);
         const std::size_t lightsAt = staging.append(lights.lights.data(), lights.lights.size() * sizeof(rt_gpu_light));
+        // room for the index that replaces the walks over the light list, built on the device below
+        std::size_t lightIndexBytes = 0;
+        engineOk(rt_light_index_bytes(static_cast<std::uint32_t>(lights.lights.size()), &lightIndexBytes), "rt_light_index_bytes");
+        lightIndexAt = lights.lights.empty() ? 0 : staging.reserve<unsigned char>(lightIndexBytes);
 
         meshes.resize(scene.geometries.size());
         for (std::size_t g = 0; g < scene.geometries.size(); ++g) {
@@ -557,6 +564,15 @@ struct Renderer::Impl {
         launch.lightCount = static_cast<std::uint32_t>(lights.lights.size());
         launch.lightWeight = lights.total;
         launch.lights = lights.lights.empty() ? nullptr : scenePool.at<const rt_gpu_light>(lightsAt);
+        lightIndex = nullptr;
+        // RT_LIGHT_INDEX=0 keeps the walks over the light list (for comparison; the image is the same)
+        const char* indexChoice = std::getenv("RT_LIGHT_INDEX");
+        if (!lights.lights.empty() && !(indexChoice && indexChoice[0] == '0')) {
+            lightIndex = scenePool.at<void>(lightIndexAt);
+            engineOk(rt_light_index_build(launch.lights, launch.lightCount, scenePool.at<void>(lightIndexAt), lightIndexBytes,
+                                          nullptr),
+                     "rt_light_index_build");
+        }
     }
 
     // One bottom-level tree per geometry, the tree over the instances, and the per-geometry records
@@ -637,9 +653,12 @@ struct Renderer::Impl {
 
     void shareBucketBits() {
         for (Part& part : parts)
-            if (part.wavefront)
+            if (part.wavefront) {
                 engineOk(rt_wavefront_set_bucket_bitmap(part.wavefront, photonPool.at<const std::uint32_t>(photonAt.bucketBits)),
                          "rt_wavefront_set_bucket_bitmap");
+                engineOk(rt_wavefront_set_light_index(part.wavefront, lightIndex, launch.lightCount),
+                         "rt_wavefront_set_light_index");
+            }
     }
 
     void applyProfile(Profile profile) {  // renderer.cpp:226, 251, 735-737
@@ -689,6 +708,7 @@ struct Renderer::Impl {
                 rt_wavefront_destroy(photonWavefront);
             photonWavefront = nullptr;
             engineOk(rt_wavefront_create(wanted, &photonWavefront), "rt_wavefront_create");
+            engineOk(rt_wavefront_set_light_index(photonWavefront, lightIndex, launch.lightCount), "rt_wavefront_set_light_index");
             photonWavefrontCapacity = wanted;
         }
         rt_launch_params pass = launch;

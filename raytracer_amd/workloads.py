@@ -336,6 +336,23 @@ def sphere_field(count=500, seed=3, subdivisions=4, sky=False):
                 environment=environment)
 
 
+def glowing_spheres_room(subdivisions=5, spheres=2):
+    """The Cornell box lit by emissive icospheres instead of its point light: 20 * 4^subdivisions emissive
+    triangles per sphere (20,480 at the default), every one of them an entry of the light list."""
+    scene = cornell_box(light="point")
+    scene["lights"] = []
+    sphere = icosphere(subdivisions)
+    scene["materials"].append(default_material(baseColor=(0, 0, 0, 1), emissive=(1.0, 0.8, 0.6), emissiveStrength=6.0))
+    scene["materials"].append(default_material(baseColor=(0, 0, 0, 1), emissive=(0.5, 0.7, 1.0), emissiveStrength=9.0))
+    first = len(scene["materials"]) - 2
+    places = [(-0.45, 1.55, 0.1, 0.22), (0.5, 1.3, -0.2, 0.15), (0.0, 0.35, 0.6, 0.1)]
+    for k in range(spheres):
+        scene["geometries"].append({"vertices": sphere[0], "indices": sphere[1], "material": first + k % 2})
+        x, y, z, r = places[k % len(places)]
+        scene["instances"].append((len(scene["geometries"]) - 1, translation(x, y, z, r)))
+    return scene
+
+
 def triangle_soup(n, seed=4):
     """n unshared triangles: centroids uniform in the unit cube, edge length
     ~ U(0.5, 1.5) * n^(-1/3)."""
