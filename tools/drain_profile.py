@@ -6,6 +6,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("RT_BENCH_ROOT"):
+    sys.path.insert(0, os.path.abspath(os.environ["RT_BENCH_ROOT"]))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import torch
