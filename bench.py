@@ -375,8 +375,8 @@ def main():
         return
 
     trace_ms, trace_launches = stages["trace"]
-    traffic = profiled_traffic() if (args.workload == "dragon-cornell" and (args.width, args.height) == (1920, 1080)
-                                     and world == 1) else None
+    profiled_workload = args.workload == "dragon-cornell" and (args.width, args.height) == (1920, 1080) and world == 1
+    traffic = profiled_traffic() if profiled_workload else None
     achieved = staged_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
     avg_launch_s = trace_ms * 1e-3 / max(trace_launches, 1)
     p = renderer.launch_params()
@@ -427,7 +427,8 @@ def main():
             "traffic": traffic[0] if traffic else None,
             "traffic_source": (f"bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {traffic[1]}, taken with "
                                f"the library this run loaded" if traffic else
-                               "no committed PMC summary was taken with the library this run loaded"),
+                               "no committed PMC summary was taken with the library this run loaded" if profiled_workload else
+                               "the committed PMC summaries are of the default workload on one GPU"),
             "traffic_gbs": traffic[0] / avg_launch_s / 1e9 if traffic else None,
             "traffic_frac_of_peak": traffic[0] / avg_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None,
             "copy_ceiling_gbs": ceiling,
