@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--photons", type=int, default=1 << 23)
     p.add_argument("--tiles", type=int, default=1,
                    help="regions of the frame that run side by side per render() call")
+    p.add_argument("--batch", type=int, default=None,
+                   help="samples a wavefront pass takes (default: 1 on one GPU, 4 when several GPUs share the frame)")
     p.add_argument("--in-flight", type=int, default=4,
                    help="consecutive samples of a region in flight at once (each on a stream of its own)")
     p.add_argument("--shared", action="store_true",
@@ -276,7 +278,7 @@ def main():
     budget = (1 << 24, 1 << 23, 1 << 22) if profile == R.FINAL else None
     if world > 1 or args.shared:
         # the ranks share every frame: bands of eight rows dealt out in turn, emission ranges per rank
-        shared = D.DistributedRenderer(scene, args.width, args.height, profile, photon_budget=budget)
+        shared = D.DistributedRenderer(scene, args.width, args.height, profile, photon_budget=budget, batch=args.batch)
         renderer = shared.renderer
         step = shared.render
     else:
@@ -284,6 +286,8 @@ def main():
         renderer = R.Renderer(scene, args.width, args.height, profile)
         if budget:
             renderer.set_photon_budget(*budget)
+        if args.batch:
+            renderer.set_sample_batch(args.batch)
         step = renderer.render
 
     # traversal averages per ray (for the algorithmic byte count), outside the timed region
@@ -340,6 +344,8 @@ def main():
     # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
     # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
     # bracketed by HIP events on the stream it runs on.
+    batch = renderer.sample_batch()
+    renderer.set_sample_batch(1)  # a launch of the staged steps is a launch over one sample
     renderer.set_concurrent_tiles(1)
     renderer.set_measurement(time_stages=True)
     step()
@@ -416,6 +422,7 @@ def main():
         "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
         "concurrent_tiles": args.tiles,
         "samples_in_flight": args.in_flight,
+        "samples_per_pass": batch,
         "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {
             "bound": "hbm",

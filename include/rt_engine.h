@@ -287,6 +287,16 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
+/* Later rt_render_sample* calls on this state render `samples` consecutive
+ * samples of their pixels in one pass: sample params->sample + k is seeded
+ * with seedSample + k * seedStride, k < samples, and the samples enter the
+ * running means in that order, so the buffers end up as after `samples` calls
+ * of one sample each (src/device.cu:1043-1046).  The state must hold pixels x
+ * samples paths.  One pass over four samples of a small pixel range (one
+ * GPU's share of a frame that several GPUs cut up) costs little more than a
+ * pass over one, because a pass is as long as its slowest rays.  The default
+ * is (1, 1).  No counterpart upstream. */
+rt_status rt_wavefront_set_sample_batch(rt_wavefront* wavefront, uint32_t samples, uint32_t seedStride);
 /* Orders the accumulation step of later rt_render_sample* calls on this state
  * against other streams: before the running means are updated the stream
  * waits for the HIP event `waitFor`, and behind the update it records the HIP

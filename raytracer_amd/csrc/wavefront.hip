@@ -126,13 +126,17 @@ __device__ inline void allocateSlotPair(bool wantA, uint32_t* counterA, bool wan
 // index.
 struct PixelMap {
     uint32_t begin;       // first pixel of the first band
-    uint32_t count;       // paths of the launch
+    uint32_t count;       // paths of the launch: perSample for each of its samples, sample after sample
+    uint32_t perSample;   // pixels of the launch
+    uint32_t samples;     // consecutive samples of these pixels that the launch renders (at least 1)
+    uint32_t seedStride;  // the seeding sample index grows by this from one of them to the next
     uint32_t width;       // image width
     uint32_t bandPaths;   // paths in the tile-numbered bands (a multiple of 8 * width), then the tail
     uint32_t bandStride;  // pixels from one band of the launch to the next (8 * width when contiguous)
     uint32_t tailBegin;   // first pixel of the row-major tail
     uint32_t tiled;       // 0 when the width is no multiple of 8: the bands then keep row-major order too
 
+    // pixel of path i of one sample, i < perSample
     __device__ uint32_t pixel(uint32_t i) const {
         if (i >= bandPaths)
             return tailBegin + (i - bandPaths);
@@ -158,9 +162,10 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     }
     if (i >= count)
         return;
-    const uint32_t index = map.pixel(i);
+    const uint32_t batch = i / map.perSample;
+    const uint32_t index = map.pixel(i - batch * map.perSample);
     const uint32_t px = index % p.width, py = index / p.width;
-    uint32_t rng = index * 9781U + seedSample * 6271U + 0x68bc21ebU;
+    uint32_t rng = index * 9781U + (seedSample + batch * map.seedStride) * 6271U + 0x68bc21ebU;
     const float jx = random01(rng);
     const float jy = random01(rng);
     const float sx = (static_cast<float>(px) + jx) / static_cast<float>(p.width);
@@ -635,32 +640,37 @@ __global__ void advanceKernel(Buffers b, int which) {
 
 // device.cu:1043-1074: running means of the seven buffers and the tone-mapped byte image.
 __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params p, PixelMap map, Buffers b) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= map.count)
+    const uint32_t pixelPath = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixelPath >= map.perSample)
         return;
-    const uint32_t index = map.pixel(i);
-    const float weight = 1.0f / static_cast<float>(p.sample + 1U);
-    const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
-    const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
-    const V3 sample = r0 + r1 + r2 + caustic;
-    auto blend = [&](rt_float4* buffer, V3 value) {
-        const V3 previous = rgb(buffer[index]);
-        const V3 next = previous + (value - previous) * weight;
-        rt_float4 out;
-        out.x = next.x;
-        out.y = next.y;
-        out.z = next.z;
-        out.w = 1.0f;
-        buffer[index] = out;
-        return next;
-    };
-    const V3 accumulated = blend(p.accumulation, sample);
-    blend(p.diffuse, r0);
-    blend(p.reflection, r1);
-    blend(p.refraction, r2);
-    blend(p.caustics, caustic);
-    blend(p.albedoGuide, albedo);
-    blend(p.normalGuide, normal);
+    const uint32_t index = map.pixel(pixelPath);
+    V3 accumulated{0.0f, 0.0f, 0.0f};
+    // the samples of a launch enter a pixel's means one after the other, in sample order
+    for (uint32_t batch = 0; batch < map.samples; ++batch) {
+        const uint32_t i = batch * map.perSample + pixelPath;
+        const float weight = 1.0f / static_cast<float>(p.sample + batch + 1U);
+        const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
+        const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
+        const V3 sample = r0 + r1 + r2 + caustic;
+        auto blend = [&](rt_float4* buffer, V3 value) {
+            const V3 previous = rgb(buffer[index]);
+            const V3 next = previous + (value - previous) * weight;
+            rt_float4 out;
+            out.x = next.x;
+            out.y = next.y;
+            out.z = next.z;
+            out.w = 1.0f;
+            buffer[index] = out;
+            return next;
+        };
+        accumulated = blend(p.accumulation, sample);
+        blend(p.diffuse, r0);
+        blend(p.reflection, r1);
+        blend(p.refraction, r2);
+        blend(p.caustics, caustic);
+        blend(p.albedoGuide, albedo);
+        blend(p.normalGuide, normal);
+    }
     if (p.output) {
         const V3 mapped = acesTonemap(accumulated * exp2f(p.exposure));
         rt_uchar4 out;
@@ -856,6 +866,7 @@ struct rt_wavefront {
     int device = 0;
     uint32_t flags = 0;               // RT_WAVEFRONT_TIME_STAGES | RT_WAVEFRONT_COUNT_TRAVERSAL
     uint32_t shareNumerator = 1, shareDenominator = 1;  // part of the resident wave slots a ray launch takes
+    uint32_t batchSamples = 1, batchSeedStride = 1;     // consecutive samples a render call takes in one pass
     hipEvent_t accumulateAfter = nullptr;   // the accumulation of a sample waits for this event (or null)
     hipEvent_t accumulateSignal = nullptr;  // ... and records this one behind it (or null)
     std::vector<StageTiming> timings; // pending event pairs (flag TIME_STAGES)
@@ -975,6 +986,16 @@ rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32
         return failInvalid("the share of a ray launch is a fraction in (0, 1]");
     w->shareNumerator = numerator;
     w->shareDenominator = denominator;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_sample_batch(rt_wavefront* w, uint32_t samples, uint32_t seedStride) {
+    if (!w)
+        return failInvalid("null pointer");
+    if (samples == 0 || samples > 64)
+        return failInvalid("a batch holds 1 to 64 samples");
+    w->batchSamples = samples;
+    w->batchSeedStride = seedStride;
     return RT_SUCCESS;
 }
 
@@ -1119,9 +1140,16 @@ rt_status rt_render_sample(rt_wavefront* w, const rt_launch_params* params, uint
     return rt_render_sample_seeded(w, params, pixelBegin, pixelEnd, params->sample, stream);
 }
 
-// One sample for the paths of `map` (its count is at least 1 and at most the capacity).
-static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, const rt_scene* scene, const PixelMap& map,
+// The samples of the wavefront's batch for the pixels of `pixels` (perSample set, at least 1 path): fills in the
+// batch and checks it against the capacity.
+static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, const rt_scene* scene, const PixelMap& pixels,
                              uint32_t seedSample, hipStream_t s) {
+    PixelMap map = pixels;
+    map.samples = w->batchSamples;
+    map.seedStride = w->batchSeedStride;
+    if (static_cast<uint64_t>(map.perSample) * map.samples > w->buffers.capacity)
+        return failInvalid("pixels x samples of the batch larger than the wavefront capacity");
+    map.count = map.perSample * map.samples;
     const uint32_t count = map.count;
     const Buffers& b = w->buffers;
     const unsigned blocks = divUp(count, kShadeBlock);
@@ -1172,7 +1200,7 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
         RT_HIP(hipStreamWaitEvent(s, w->accumulateAfter, 0));
     {
         StageTimer timer(w, s, 4);
-        hipLaunchKernelGGL(accumulateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, map, b);
+        hipLaunchKernelGGL(accumulateKernel, dim3(divUp(map.perSample, kShadeBlock)), dim3(kShadeBlock), 0, s, *params, map, b);
     }
     RT_HIP(hipGetLastError());
     if (w->accumulateSignal)
@@ -1206,9 +1234,9 @@ rt_status rt_render_sample_seeded(rt_wavefront* w, const rt_launch_params* param
     if (count > w->buffers.capacity)
         return failInvalid("pixel range larger than the wavefront capacity");
     const uint32_t width = params->width, band = 8U * width;
-    PixelMap map;
+    PixelMap map{};
     map.begin = pixelBegin;
-    map.count = count;
+    map.perSample = count;
     map.width = width;
     // full bands first when the range starts on a row and rows split into 8-pixel tiles
     map.bandPaths = (pixelBegin % width == 0U && width % 8U == 0U) ? count / band * band : 0U;
@@ -1237,9 +1265,9 @@ rt_status rt_render_sample_bands(rt_wavefront* w, const rt_launch_params* params
     if (count > w->buffers.capacity)
         return failInvalid("bands larger than the wavefront capacity");
     const uint32_t band = 8U * width;
-    PixelMap map;
+    PixelMap map{};
     map.begin = firstBand * band;
-    map.count = static_cast<uint32_t>(count);
+    map.perSample = static_cast<uint32_t>(count);
     map.width = width;
     map.bandStride = bandStride * band;
     map.tailBegin = lastBand * band;  // only used when the last band is short

@@ -137,7 +137,8 @@ class DistributedRenderer:
     """rt::Renderer sharded over the ranks of a process group.  Same calls as the single-GPU class:
     render(), linear_pixels(), samples()."""
 
-    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None, in_flight=4):
+    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None, in_flight=4,
+                 batch=None):
         import torch
         import torch.distributed as dist
         from . import renderer as R
@@ -153,6 +154,9 @@ class DistributedRenderer:
             self.renderer.set_photon_budget(*photon_budget)
         if tiles is not None:
             self.renderer.set_concurrent_tiles(tiles, in_flight)
+        # A rank's share of the frame shrinks with the number of ranks, and a pass over few pixels is as long
+        # as its slowest rays: from two ranks on, four samples go into one pass (same image).
+        self.renderer.set_sample_batch(batch if batch is not None else (4 if self.world > 1 else 1))
         self.renderer.set_manual_photon_passes(True)
         self.renderer.set_row_interleave(self.rank, self.world)
         self.exchanges = []  # per photon pass: dict(ms, photons, kept, bytes_sent, bytes_received)

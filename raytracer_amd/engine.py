@@ -80,6 +80,7 @@ SYMBOLS = {
     "rt_wavefront_set_light_index": (C.c_int, [_vp, _vp, _u32]),
     "rt_light_query": (C.c_int, [_vp, _u32, C.c_float, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rt_wavefront_set_accumulate_events": (C.c_int, [_vp, _vp, _vp]),
+    "rt_wavefront_set_sample_batch": (C.c_int, [_vp, _u32, _u32]),
     "rt_streams_run_concurrently": (C.c_int, [_vp, _u32, _vp]),
     "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
 }

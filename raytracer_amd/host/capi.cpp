@@ -434,6 +434,10 @@ int rth_renderer_set_parts_and_depth(rt::Renderer* r, uint32_t count, uint32_t s
     return guarded([&] { r->setConcurrentTiles(count, samplesInFlight); });
 }
 uint32_t rth_renderer_samples_in_flight(rt::Renderer* r) { return r->samplesInFlight(); }
+int rth_renderer_set_sample_batch(rt::Renderer* r, uint32_t samples) {
+    return guarded([&] { r->setSampleBatch(samples); });
+}
+uint32_t rth_renderer_sample_batch(rt::Renderer* r) { return r->sampleBatch(); }
 uint32_t rth_renderer_concurrent_tiles(rt::Renderer* r) { return r->concurrentTiles(); }
 int rth_renderer_set_ray_share(rt::Renderer* r, uint32_t numerator, uint32_t denominator) {
     return guarded([&] { r->setRayShare(numerator, denominator); });

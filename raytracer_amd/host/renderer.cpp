@@ -431,6 +431,19 @@ struct Renderer::Impl {
     };
     std::vector<Part> parts;
     std::uint32_t partCount = 0, depth = 1;
+    // render() calls are collected into passes of up to `batch` samples (setSampleBatch; 1: every call is a
+    // pass of its own): `pending` calls wait for their pass, which goes out when it is full, before a photon
+    // pass, and whenever the image, the counters or the GPU are asked for.
+    std::uint32_t batch = 1, pending = 0, passes = 0;
+    std::uint32_t batchWanted = 0;  // what setSampleBatch asked for; 0: as many as kStateBudget allows
+    void* pendingTarget = nullptr;
+    // The parts are created when the first pass goes out, for the pixels render() covers by then, and again
+    // when that grows or shrinks to less than half: a GPU that takes one share of many has state for its share.
+    std::uint64_t partCapacity = 0;                     // pixels one part has room for
+    std::uint32_t shareNumerator = 0, shareDenominator = 0;  // setRayShare; 0: the policy of createParts
+    // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x 328 bytes
+    static constexpr std::uint64_t kStateBudget = 12ULL << 30;
+    static constexpr std::uint64_t kStateBytesPerPath = 328;
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
     // launches leave the GPU half idle in their tails; four of them side by side fill it)
@@ -474,7 +487,8 @@ struct Renderer::Impl {
         launch.sceneRadius = sphere.radius;
         setPhotonSizes(1U << 24U, 1U << 23U, 1U << 22U);  // renderer.cpp:533-535
         allocateFrame();
-        createParts(kDefaultParts, kDefaultDepth);
+        partCount = kDefaultParts;
+        depth = kDefaultDepth;
         applyProfile(profile);
         applyCamera(scene.cameras.front());
         restart();
@@ -688,11 +702,13 @@ struct Renderer::Impl {
         launch.photonPass = 0;
         launch.photonRadius = caustics ? gatherRadius : 0.0f;
         sample = 0;
+        pending = 0;  // calls that were still waiting belonged to the sequence that ends here
     }
 
     // ---- photon pass (renderer.cpp:741-777), in the three steps a multi-GPU driver interleaves with
     // its exchange
     void beginPhotonPass() {  // :742-745
+        flush();  // the samples that are waiting read the map this pass replaces
         launch.photonRadius = gatherRadius;
         hipOk(hipMemset(photonPool.at<void>(photonAt.counter), 0, sizeof(std::uint32_t)));
     }
@@ -741,12 +757,13 @@ struct Renderer::Impl {
     }
 
     bool photonPassDue() const {  // renderer.cpp:780
-        return launch.photonRadius > 0.0f && sample % kPhotonRebuildInterval == 0U;
+        return launch.photonRadius > 0.0f && (sample + pending) % kPhotonRebuildInterval == 0U;
     }
 
     // ---- one sample (renderer.cpp:779-796) --------------------------------------------------------------
     void render(void* target) {
         if (photonPassDue()) {
+            flush();
             if (!manualPhotonPasses) {
                 beginPhotonPass();
                 finishPhotonPass(tracePhotonRange(0, launch.photonEmissions, false));
@@ -754,6 +771,22 @@ struct Renderer::Impl {
                 raise("a photon pass is due: run beginPhotonPass/tracePhotonRange/finishPhotonPass");
             }
         }
+        if (parts.empty())
+            ensureParts();  // sets the number of samples a pass takes
+        pendingTarget = target;
+        ++pending;
+        photonPassPending = true;
+        // a caller's own target is written by the pass this call belongs to, so that pass goes out now
+        if (pending >= batch || target)
+            flush();
+    }
+
+    // Sends the waiting render() calls off as one pass over their samples.
+    void flush() {
+        if (pending == 0)
+            return;
+        ensureParts();
+        void* const target = pendingTarget;
         launch.display = nullptr;
         launch.display2 = nullptr;
         launch.display3 = nullptr;
@@ -765,9 +798,10 @@ struct Renderer::Impl {
         // with the other parts' work instead of idling the GPU.  The streams are ordinary (blocking)
         // ones: work on the default stream before and after still orders against them.
         const std::uint32_t count = partCount;
-        const std::uint32_t set = sample % depth, before = (sample + depth - 1U) % depth;
+        const std::uint32_t set = passes % depth, before = (passes + depth - 1U) % depth;
         auto partOf = [&](std::uint32_t k) -> Part& {
             Part& part = parts[set * count + k];
+            engineOk(rt_wavefront_set_sample_batch(part.wavefront, pending, sampleStride), "rt_wavefront_set_sample_batch");
             if (depth > 1U) {
                 // this region's previous sample was accumulated by the part of the set before this one
                 Part& previous = parts[before * count + k];
@@ -800,8 +834,10 @@ struct Renderer::Impl {
                     part.recorded = false;  // nothing was enqueued, so nothing records the event
             }
         }
-        ++sample;
-        photonPassPending = true;
+        sample += pending;
+        pending = 0;
+        pendingTarget = nullptr;
+        ++passes;
     }
 
     // ---- the concurrent parts of a frame ------------------------------------------------------------------
@@ -817,27 +853,54 @@ struct Renderer::Impl {
         parts.clear();
     }
 
-    void createParts(std::uint32_t count, std::uint32_t samplesInFlight = 1) {
+    // Pixels one part must have room for: an even share of what render() covers.
+    std::uint64_t neededCapacity() const {
+        const std::uint64_t count = partCount;
+        if (rangeSet)
+            return std::max<std::uint64_t>(1, (rangeEnd - rangeBegin + count - 1U) / count);
+        const std::uint64_t bands = (height + kBandRows - 1U) / kBandRows;
+        const std::uint64_t mine = firstBand < bands ? (bands - 1U - firstBand) / bandStride + 1U : 0U;
+        return std::max<std::uint64_t>(1, (mine + count - 1U) / count * kBandRows * width);
+    }
+
+    void ensureParts() {
+        const std::uint64_t needed = neededCapacity();
+        if (parts.empty() || needed > partCapacity || needed * 2U < partCapacity)
+            createParts(needed);
+    }
+
+    void dropParts() {
         hipOk(hipDeviceSynchronize());
         destroyParts();
-        count = std::clamp<std::uint32_t>(count, 1U, 8U);
-        depth = std::clamp<std::uint32_t>(samplesInFlight, 1U, 8U);
-        partCount = count;
-        // room for the larger of an even share of the pixels and an even share of the bands
-        const std::uint64_t pixels = static_cast<std::uint64_t>(width) * height;
-        const std::uint64_t bands = (height + kBandRows - 1U) / kBandRows;
-        const std::uint64_t capacity =
-            std::min(pixels, std::max((pixels + count - 1U) / count, (bands + count - 1U) / count * kBandRows * width));
+        partCapacity = 0;
+    }
+
+    void createParts(std::uint64_t capacity) {
+        hipOk(hipDeviceSynchronize());
+        destroyParts();
+        const std::uint32_t count = partCount;
+        partCapacity = capacity;
+        // samples per pass: what was asked for, else the most of 8, 4, 2, 1 whose state fits the budget
+        batch = batchWanted;
+        if (batch == 0) {
+            batch = 8;
+            while (batch > 1 && capacity * count * depth * batch * kStateBytesPerPath > kStateBudget)
+                batch /= 2;
+        }
         parts.resize(static_cast<std::size_t>(count) * depth);
         if (parts.size() > 1)
             pickStreams();
         for (Part& part : parts) {
-            engineOk(rt_wavefront_create(static_cast<std::uint32_t>(capacity), &part.wavefront), "rt_wavefront_create");
+            if (capacity * batch > 0xffffffffULL)
+                raise("sample batch: pixels x samples of a pass do not fit 32 bits");
+            engineOk(rt_wavefront_create(static_cast<std::uint32_t>(capacity * batch), &part.wavefront), "rt_wavefront_create");
             engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
             // a single part stays on the default stream; parts that run side by side take half the wave
             // slots per ray launch: two of them then trace side by side, each filling the slots the
             // other's last rays leave idle
-            if (parts.size() > 1)
+            if (shareNumerator)
+                engineOk(rt_wavefront_set_ray_share(part.wavefront, shareNumerator, shareDenominator), "rt_wavefront_set_ray_share");
+            else if (parts.size() > 1)
                 engineOk(rt_wavefront_set_ray_share(part.wavefront, 1, 2), "rt_wavefront_set_ray_share");
             if (depth > 1)
                 hipOk(hipEventCreateWithFlags(&part.accumulated, hipEventDisableTiming));
@@ -899,22 +962,25 @@ void Renderer::setProfile(Profile profile) {  // renderer.cpp:735-739
 }
 
 void Renderer::copyOutput(void* output) const {  // renderer.cpp:888-891: device to device
+    impl_->flush();
     hipOk(hipMemcpy(output, impl_->framePool.at<void>(impl_->outputOffset), impl_->outputBytes, hipMemcpyDeviceToDevice));
 }
 
 std::vector<std::uint8_t> Renderer::pixels() const {  // renderer.cpp:881-886
+    impl_->flush();
     std::vector<std::uint8_t> image(impl_->outputBytes);
     hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->outputOffset), image.size(), hipMemcpyDeviceToHost));
     return image;
 }
 
 std::vector<float> Renderer::linearPixels() const {  // renderer.cpp:893-899
+    impl_->flush();
     std::vector<float> image(impl_->aovBytes / sizeof(float));
     hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->aovOffset[0]), impl_->aovBytes, hipMemcpyDeviceToHost));
     return image;
 }
 
-std::uint32_t Renderer::samples() const { return impl_->sample; }
+std::uint32_t Renderer::samples() const { return impl_->sample + impl_->pending; }
 
 void Renderer::setPhotonBudget(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets) {
     if (emissions == 0 || capacity == 0 || buckets == 0 || (buckets & (buckets - 1U)) != 0)
@@ -961,12 +1027,17 @@ void Renderer::finishPhotonPass(std::uint32_t totalPhotons) { impl_->finishPhoto
 void* Renderer::accumulationBuffer(int index) const {
     if (index < 0 || index > 6)
         raise("accumulation buffer index");
+    impl_->flush();  // what reads the buffer behind this call finds every sample on its way
     return impl_->framePool.at<void>(impl_->aovOffset[static_cast<std::size_t>(index)]);
 }
 
-void* Renderer::outputBuffer() const { return impl_->framePool.at<void>(impl_->outputOffset); }
+void* Renderer::outputBuffer() const {
+    impl_->flush();
+    return impl_->framePool.at<void>(impl_->outputOffset);
+}
 
 void Renderer::statistics(std::uint64_t out[8]) {
+    impl_->flush();
     std::fill(out, out + 8, std::uint64_t{0});
     auto add = [&](rt_wavefront* state, hipStream_t stream) {
         std::uint64_t part[8] = {};
@@ -988,6 +1059,7 @@ void Renderer::setMeasurement(bool timeStages, bool countTraversal, bool gatherP
 }
 
 void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
+    impl_->flush();
     std::fill(milliseconds, milliseconds + 5, 0.0f);
     std::fill(launches, launches + 5, 0U);
     for (auto& part : impl_->parts) {
@@ -1002,18 +1074,42 @@ void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
 }
 
 void Renderer::setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight) {
-    impl_->createParts(count, samplesInFlight);
+    impl_->dropParts();
+    impl_->partCount = std::clamp<std::uint32_t>(count, 1U, 8U);
+    impl_->depth = std::clamp<std::uint32_t>(samplesInFlight, 1U, 8U);
+    impl_->shareNumerator = impl_->shareDenominator = 0;
     impl_->restart();
 }
 
+void Renderer::setSampleBatch(std::uint32_t samples) {
+    if (samples > 64)
+        raise("sample batch: at most 64 samples");
+    impl_->dropParts();
+    impl_->batchWanted = samples;
+    impl_->restart();
+}
+
+std::uint32_t Renderer::sampleBatch() const {
+    impl_->flush();
+    impl_->ensureParts();
+    return impl_->batch;
+}
+
 void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
+    if (numerator == 0 || denominator == 0 || numerator > denominator)
+        raise("the share of a ray launch is a fraction in (0, 1]");
+    impl_->shareNumerator = numerator;
+    impl_->shareDenominator = denominator;
     for (auto& part : impl_->parts)
         engineOk(rt_wavefront_set_ray_share(part.wavefront, numerator, denominator), "rt_wavefront_set_ray_share");
 }
 
 std::uint32_t Renderer::concurrentTiles() const { return impl_->partCount; }
 std::uint32_t Renderer::samplesInFlight() const { return impl_->depth; }
-void Renderer::synchronize() const { hipOk(hipDeviceSynchronize()); }
+void Renderer::synchronize() const {
+    impl_->flush();
+    hipOk(hipDeviceSynchronize());
+}
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }
 float Renderer::causticRadius() const { return impl_->gatherRadius; }
 

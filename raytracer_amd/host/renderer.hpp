@@ -54,6 +54,7 @@ public:
     // frame in turn, which spreads rows that are dear to trace over all of them.  Replaces a pixel
     // range; (0, 1), the default, is the whole frame.
     void setRowInterleave(std::uint32_t first, std::uint32_t stride);
+    // (The wavefront state is created with the first pass, for the pixels render() covers by then.)
     // render() cuts its pixel range into `count` parts (1..8, default 1) that run
     // concurrently on streams of their own; the image does not depend on it.
     // With more than one part the stage timings of the parts overlap in time.
@@ -64,6 +65,18 @@ public:
     // The default is one region with four samples in flight.
     void setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight = 1);
     std::uint32_t samplesInFlight() const;
+    // render() calls are collected into passes of up to `samples` consecutive samples (1 to 64) that the GPU
+    // takes in one go: the pixels' means take the samples in order as before, so the image does not change,
+    // but a pass is as long as its slowest rays however few pixels it covers, and a pass over four samples
+    // costs less than four passes (1080p: 2.76 -> 2.55 ms per sample; an eighth of the frame, as one of eight
+    // GPUs renders it: 0.58 -> 0.35 ms).  0, the default, takes the most of 8, 4, 2, 1 samples for which
+    // the wavefront state (328 bytes x pixels covered x samples per pass x passes in flight) stays below
+    // 12 GiB.  A pass goes out when it is full, before a photon pass, with a render() call that names a
+    // target of the caller, and whenever the image, the counters or the GPU are asked for (pixels(),
+    // linearPixels(), copyOutput(), accumulationBuffer(), outputBuffer(), statistics(), stageTimings(),
+    // synchronize()).  Restarts the accumulation.
+    void setSampleBatch(std::uint32_t samples);
+    std::uint32_t sampleBatch() const;
     // Share of the GPU's wave slots a ray launch of one part takes (setConcurrentTiles
     // resets it: 1/2 for a split frame, 1/1 otherwise).
     void setRayShare(std::uint32_t numerator, std::uint32_t denominator);

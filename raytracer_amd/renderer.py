@@ -117,6 +117,8 @@ _SIG = {
     "rth_renderer_concurrent_tiles": (_u32, [_vp]),
     "rth_renderer_set_parts_and_depth": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_samples_in_flight": (_u32, [_vp]),
+    "rth_renderer_set_sample_batch": (C.c_int, [_vp, _u32]),
+    "rth_renderer_sample_batch": (_u32, [_vp]),
     "rth_renderer_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
     "rth_renderer_set_manual_photon_passes": (None, [_vp, C.c_int]),
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
@@ -421,6 +423,14 @@ class Renderer:
         """render() cuts its pixels into `count` regions that run side by side; with samples_in_flight > 1
         that many consecutive samples of a region may run at once.  Restarts the accumulation."""
         _check(load().rth_renderer_set_parts_and_depth(self.handle, count, samples_in_flight))
+
+    def set_sample_batch(self, samples):
+        """render() calls are collected into passes of up to `samples` samples that the GPU takes in one go
+        (same image; for a GPU that renders a small share of a frame).  Restarts the accumulation."""
+        _check(load().rth_renderer_set_sample_batch(self.handle, samples))
+
+    def sample_batch(self):
+        return int(load().rth_renderer_sample_batch(self.handle))
 
     def samples_in_flight(self):
         return int(load().rth_renderer_samples_in_flight(self.handle))

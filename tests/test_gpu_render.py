@@ -498,6 +498,70 @@ def test_concurrent_tiles_do_not_change_the_image(R):
     assert images[0][1]["gather_queries"] > 0
 
 
+def test_sample_batches_do_not_change_the_image(R):
+    """render() calls collected into passes of 1, 2, 3, 4 or 8 samples (one wavefront pass over pixels x samples
+    paths, the means taking the samples in order), alone and with passes in flight and a frame cut into parts:
+    bit-identical buffers and byte image after 11 samples, the same ray counts, samples() counting calls
+    that still wait; the final profile, whose photon passes fall between samples 3 | 4 and 7 | 8 and cut a
+    pass short; a band-interleaved share and a pixel range."""
+    import torch
+    scene = workloads.cornell_box(light="panel")
+    w, h = 64, 72
+    shots = []
+    for batch, tiles, depth in ((1, 1, 1), (2, 1, 1), (3, 1, 1), (4, 1, 1), (8, 1, 1), (4, 1, 3), (2, 2, 2)):
+        r = R.Renderer(scene, w, h)
+        r.set_concurrent_tiles(tiles, depth)
+        r.set_sample_batch(batch)
+        assert r.sample_batch() == batch
+        for k in range(11):
+            r.render()
+            assert r.samples() == k + 1
+        shots.append((r.linear_pixels().copy(), r.pixels().copy(), r.statistics()))
+    for pixels, bytes8, stats in shots[1:]:
+        assert np.array_equal(pixels, shots[0][0]) and np.array_equal(bytes8, shots[0][1])
+        assert stats["extend_rays"] == shots[0][2]["extend_rays"] and stats["shadow_rays"] == shots[0][2]["shadow_rays"]
+    # a caller's own target closes the pass it belongs to
+    r = R.Renderer(scene, w, h)
+    r.set_sample_batch(4)
+    mine = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    for k in range(11):
+        r.render(mine if k == 10 else None)
+    torch.cuda.synchronize()
+    assert np.array_equal(mine.cpu().numpy().reshape(-1), shots[0][1].reshape(-1))
+    # final profile: photon passes before samples 0, 4 and 8
+    scene = workloads.caustic_lab()
+    w, h = 64, 40
+    shots = []
+    for batch, depth in ((1, 1), (4, 1), (3, 2), (8, 4)):
+        r = R.Renderer(scene, w, h, 1)
+        r.set_photon_budget(1 << 19, 1 << 18, 1 << 14)
+        r.set_concurrent_tiles(1, depth)
+        r.set_sample_batch(batch)
+        for _ in range(10):
+            r.render()
+        r.synchronize()
+        shots.append(np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]))
+        assert r.statistics()["gather_queries"] > 0
+    for buffers in shots[1:]:
+        assert np.array_equal(buffers, shots[0])
+    # shares of a frame
+    scene = workloads.cornell_box(light="panel")
+    w, h = 64, 72
+    for share in ("bands", "range"):
+        shots = []
+        for batch in (1, 4):
+            r = R.Renderer(scene, w, h)
+            r.set_sample_batch(batch)
+            if share == "bands":
+                r.set_row_interleave(1, 3)
+            else:
+                r.set_pixel_range(5 * w + 3, 40 * w + 9)
+            for _ in range(6):
+                r.render()
+            shots.append(r.linear_pixels().copy())
+        assert np.array_equal(shots[0], shots[1]) and shots[0].any()
+
+
 def test_ray_share_does_not_change_the_image(R):
     """The share of the wave slots a ray launch takes is a scheduling matter only: a small share makes
     fewer waves walk the same rays.  Fractions outside (0, 1] are refused."""
