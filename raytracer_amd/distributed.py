@@ -154,9 +154,11 @@ class DistributedRenderer:
             self.renderer.set_photon_budget(*photon_budget)
         if tiles is not None:
             self.renderer.set_concurrent_tiles(tiles, in_flight)
-        # A rank's share of the frame shrinks with the number of ranks, and a pass over few pixels is as long
-        # as its slowest rays: from two ranks on, four samples go into one pass (same image).
-        self.renderer.set_sample_batch(batch if batch is not None else (4 if self.world > 1 else 1))
+        # A rank's share of the frame shrinks with the number of ranks, and a pass over few pixels is as long as
+        # its slowest rays: the renderer puts as many samples into a pass as its memory budget lets it for the
+        # share it covers (eight from two ranks on at 1080p; same image) unless the caller names a number.
+        if batch is not None:
+            self.renderer.set_sample_batch(batch)
         self.renderer.set_manual_photon_passes(True)
         self.renderer.set_row_interleave(self.rank, self.world)
         self.exchanges = []  # per photon pass: dict(ms, photons, kept, bytes_sent, bytes_received)

@@ -442,7 +442,7 @@ struct Renderer::Impl {
     std::uint64_t partCapacity = 0;                     // pixels one part has room for
     std::uint32_t shareNumerator = 0, shareDenominator = 0;  // setRayShare; 0: the policy of createParts
     // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x 328 bytes
-    static constexpr std::uint64_t kStateBudget = 12ULL << 30;
+    static constexpr std::uint64_t kStateBudget = 24ULL << 30;
     static constexpr std::uint64_t kStateBytesPerPath = 328;
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
@@ -883,7 +883,10 @@ struct Renderer::Impl {
         // samples per pass: what was asked for, else the most of 8, 4, 2, 1 whose state fits the budget
         batch = batchWanted;
         if (batch == 0) {
-            batch = 8;
+            // with a photon map every fourth sample starts behind a pass that waits for the GPU, and four
+            // samples in flight between two passes beat one pass over the four (3.77 against 4.42 ms per
+            // sample of the 32-bounce profile, whose late bounces are launches of a few thousand rays)
+            batch = caustics ? 1U : 8U;
             while (batch > 1 && capacity * count * depth * batch * kStateBytesPerPath > kStateBudget)
                 batch /= 2;
         }
@@ -958,6 +961,7 @@ void Renderer::setCamera(const Camera& camera) {  // renderer.cpp:730-733
 
 void Renderer::setProfile(Profile profile) {  // renderer.cpp:735-739
     impl_->applyProfile(profile);
+    impl_->dropParts();  // the samples a pass takes depend on the profile
     impl_->restart();
 }
 
