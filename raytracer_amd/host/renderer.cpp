@@ -1003,6 +1003,7 @@ void Renderer::setSampleSequence(std::uint32_t first, std::uint32_t stride) {
 void Renderer::setPixelRange(std::uint32_t begin, std::uint32_t end) {
     if (end < begin || end > impl_->width * impl_->height)
         raise("pixel range outside the image");
+    impl_->flush();  // calls that wait were made for the pixels covered so far
     impl_->rangeSet = true;
     impl_->rangeBegin = begin;
     impl_->rangeEnd = end;
@@ -1011,6 +1012,7 @@ void Renderer::setPixelRange(std::uint32_t begin, std::uint32_t end) {
 void Renderer::setRowInterleave(std::uint32_t first, std::uint32_t stride) {
     if (stride == 0 || first >= stride)
         raise("row interleave: the stride must be positive and the first band below it");
+    impl_->flush();
     impl_->rangeSet = false;
     impl_->firstBand = first;
     impl_->bandStride = stride;
