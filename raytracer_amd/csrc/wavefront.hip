@@ -26,7 +26,15 @@
 namespace rt {
 namespace {
 
-constexpr int kShadeBlock = 256;
+// Threads per workgroup of the stages between the ray launches.  A workgroup draws its slots in the next
+// queue with one atomic on the queue's counter, and atomics on one word are served one after the other:
+// the fewer workgroups a launch has, the shorter that line.
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256
+#endif
+constexpr int kShadeBlock = RT_SHADE_BLOCK;
+constexpr int kShadeWaves = kShadeBlock / 64;
+constexpr int kSlotWords = kShadeWaves + 1;  // shared words allocateSlots() needs; allocateSlotPair() twice as many
 
 // Path flags packed beside lastOrigin: bits 0-1 lobe, 2 lastDelta,
 // 3 primaryChain, 4 guidePending, bits 8.. (medium material + 1).
@@ -65,7 +73,7 @@ struct Buffers {
 
 // Slots for the lanes with `want` set: a wave ballot, a workgroup prefix and one
 // atomic on *counter per workgroup.  Every thread of the workgroup calls this.
-__device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t* shared /* 8 words */) {
+__device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t* shared /* kSlotWords */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long votes = __ballot(want);
     if (lane == 0)
@@ -73,45 +81,45 @@ __device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t*
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
-        for (int w = 0; w < kShadeBlock / 64; ++w) {
+        for (int w = 0; w < kShadeWaves; ++w) {
             const uint32_t c = shared[w];
             shared[w] = total;
             total += c;
         }
-        shared[4] = total ? atomicAdd(counter, total) : 0U;
+        shared[kShadeWaves] = total ? atomicAdd(counter, total) : 0U;
     }
     __syncthreads();
-    const uint32_t slot = shared[4] + shared[wave] + __popcll(votes & ((1ULL << lane) - 1ULL));
+    const uint32_t slot = shared[kShadeWaves] + shared[wave] + __popcll(votes & ((1ULL << lane) - 1ULL));
     __syncthreads();
     return slot;
 }
 
 // Two queues at once (the next bounce's rays and the shadow rays of a shade
 // launch): one pass through the workgroup's barriers instead of two.  `shared`
-// holds 16 words.
+// holds 2 * kSlotWords words.
 __device__ inline void allocateSlotPair(bool wantA, uint32_t* counterA, bool wantB, uint32_t* counterB,
-                                        uint32_t* shared /* 16 words */, uint32_t& slotA, uint32_t& slotB) {
+                                        uint32_t* shared /* 2 * kSlotWords */, uint32_t& slotA, uint32_t& slotB) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long votesA = __ballot(wantA), votesB = __ballot(wantB);
     if (lane == 0) {
         shared[wave] = __popcll(votesA);
-        shared[8 + wave] = __popcll(votesB);
+        shared[kSlotWords + wave] = __popcll(votesB);
     }
     __syncthreads();
     if (threadIdx.x < 2) {  // thread 0 totals queue A, thread 1 queue B
-        uint32_t* counts = shared + 8 * threadIdx.x;
+        uint32_t* counts = shared + kSlotWords * threadIdx.x;
         uint32_t total = 0;
-        for (int w = 0; w < kShadeBlock / 64; ++w) {
+        for (int w = 0; w < kShadeWaves; ++w) {
             const uint32_t c = counts[w];
             counts[w] = total;
             total += c;
         }
-        counts[4] = total ? atomicAdd(threadIdx.x == 0 ? counterA : counterB, total) : 0U;
+        counts[kShadeWaves] = total ? atomicAdd(threadIdx.x == 0 ? counterA : counterB, total) : 0U;
     }
     __syncthreads();
     const unsigned long long below = (1ULL << lane) - 1ULL;
-    slotA = shared[4] + shared[wave] + __popcll(votesA & below);
-    slotB = shared[12] + shared[8 + wave] + __popcll(votesB & below);
+    slotA = shared[kShadeWaves] + shared[wave] + __popcll(votesA & below);
+    slotB = shared[kSlotWords + kShadeWaves] + shared[kSlotWords + wave] + __popcll(votesB & below);
 }
 
 // ---- camera paths -----------------------------------------------------------
@@ -506,7 +514,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
 __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                            const rt_hit_group_data* geometries, Buffers b, int which,
                                                            uint32_t depth) {
-    __shared__ uint32_t slots[16];
+    __shared__ uint32_t slots[2 * kSlotWords];
     const uint32_t n = b.counts[which];
     if (blockIdx.x * kShadeBlock >= n)
         return;  // whole workgroup idle
@@ -687,7 +695,7 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
 // emitPhoton, device.cu:652-712, for emissions [first, first + count)
 __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_params p, uint32_t first, uint32_t count,
                                                                     Buffers b) {
-    __shared__ uint32_t slots[8];
+    __shared__ uint32_t slots[kSlotWords];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     V3 origin{0, 0, 0}, direction{0, 0, 0}, power{0, 0, 0};
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
 __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                                  const rt_hit_group_data* geometries, Buffers b,
                                                                  int which, uint32_t depth) {
-    __shared__ uint32_t slots[8];
+    __shared__ uint32_t slots[kSlotWords];
     const uint32_t n = b.counts[which];
     if (blockIdx.x * kShadeBlock >= n)
         return;
@@ -770,19 +778,27 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
         path = b.rayPath[which][slot];
         const uint4 h = b.hits[slot];
         if (h.w != kNoHit) {
+            uint32_t flags = __float_as_uint(b.lastOrigin[path].w);
+            bool specularPath = flags & 1U;
+            // A photon that has met nothing specular yet ends, without a trace, on a surface that neither
+            // transmits nor mirrors (device.cu:826-858 fall through): most photons of a pass, at their first
+            // hit.  The maps of a material only scale its metallic and transmission factors down (texels
+            // are at most one), so the factors alone say so, before the triangle's vertices are read.
+            const uint32_t hitInstance = b.hitInstance[slot];
+            const rt_gpu_material& factors = p.materials[geometries[instances[hitInstance].geometry].material];
+            const bool ends = !specularPath && !(factors.transmission > 0.0f) && !(factors.metallic > 0.5f);
+            if (!ends) {
             const float4 o4 = b.rayOrigin[which][slot];
             const float4 d4 = b.rayDirection[which][slot];
             origin = V3{o4.x, o4.y, o4.z};
             direction = V3{d4.x, d4.y, d4.z};
             const float4 pw = b.throughput[path];
             V3 power{pw.x, pw.y, pw.z};
-            uint32_t flags = __float_as_uint(b.lastOrigin[path].w);
-            bool specularPath = flags & 1U;
             int medium = static_cast<int>(flags >> 8) - 1;
             uint32_t rng = b.rng[path];
             rt_hit hit;
             reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
-                           __uint_as_float(h.z), h.w, b.hitInstance[slot], hit);
+                           __uint_as_float(h.z), h.w, hitInstance, hit);
             const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
             const V3 normal = shadingNormal(p.textures, hit, m);
             hit.normal = r3(normal);
@@ -823,6 +839,7 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
                 b.throughput[path] = make_float4(power.x, power.y, power.z, 0.0f);
                 flags = (specularPath ? 1U : 0U) | static_cast<uint32_t>(medium + 1) << 8;
                 b.lastOrigin[path] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
+            }
             }
         }
     }
