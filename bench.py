@@ -141,9 +141,13 @@ def profiled_traffic():
         lines = open(path).read().splitlines()
         if not any(line.startswith("librt_engine.so sha256") and current in line for line in lines):
             continue
+        counters = False  # the summary lists kernel times first; the counter table follows its own heading
         for line in lines:
+            if line.startswith("== per-launch PMC means"):
+                counters = True
+                continue
             f = line.split()
-            if len(f) >= 6 and f[0].startswith("traceKernel<false>"):
+            if counters and len(f) >= 6 and f[0].startswith("traceKernel<false>"):
                 try:
                     return float(f[3]) * 1e6 + float(f[4]) * 1024.0, os.path.basename(path)  # fetch_x2_MB, WRITE_KiB
                 except ValueError:
@@ -344,14 +348,17 @@ def main():
     # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
     # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
     # bracketed by HIP events on the stream it runs on.
+    # the passes keep their number of samples: a launch here is a launch of the timed region, alone on the GPU
     batch = renderer.sample_batch()
-    renderer.set_sample_batch(1)  # a launch of the staged steps is a launch over one sample
     renderer.set_concurrent_tiles(1)
+    renderer.set_sample_batch(batch)
     renderer.set_measurement(time_stages=True)
-    step()
+    for _ in range(batch):
+        step()
     renderer.stage_timings()
     renderer.statistics()
-    for _ in range(args.steps):
+    staged_steps = max(batch, args.steps // batch * batch)  # whole passes
+    for _ in range(staged_steps):
         step()
     renderer.synchronize()
     stages = renderer.stage_timings()
@@ -418,7 +425,7 @@ def main():
             "light_count": int(p.lightCount),
             "parallelism": parallelism,
         },
-        "stage_ms_per_step": {k: v[0] / args.steps for k, v in stages.items()},
+        "stage_ms_per_step": {k: v[0] / staged_steps for k, v in stages.items()},
         "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
         "concurrent_tiles": args.tiles,
         "samples_in_flight": args.in_flight,
