@@ -258,6 +258,12 @@ def cpu_gather_baseline(grid, qp, qn, radius, buckets, seconds):
 
 def main():
     args = parse()
+    # Libraries under this process write to the C stdout (RCCL prints a version banner there when a
+    # communicator comes up).  The one JSON line must be all that stdout carries: everything else goes to
+    # stderr, and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from raytracer_amd import distributed as D
@@ -477,7 +483,9 @@ def main():
             out["cpu_baseline"]["gather"] = photon.pop("cpu_baseline")
     if photon is not None:
         photon.pop("cpu_baseline", None)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     if shared:
         dist.destroy_process_group()
 
