@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--photons", type=int, default=1 << 23)
     p.add_argument("--tiles", type=int, default=1,
                    help="regions of the frame that run side by side per render() call")
+    p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                   help="nccl (RCCL) for one rank per GPU; gloo rehearses the multi-rank path with several ranks on one GPU")
     p.add_argument("--batch", type=int, default=None,
                    help="samples a wavefront pass takes (default: 1 on one GPU, 4 when several GPUs share the frame)")
     p.add_argument("--in-flight", type=int, default=4,
@@ -276,12 +278,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    local %= torch.cuda.device_count()  # more ranks than GPUs only in a gloo rehearsal
     torch.cuda.set_device(local)
+    wire = "cuda" if args.backend == "nccl" else "cpu"  # where the bench's own small collectives live
     if world > 1 or args.shared:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     R.load()
 
     scene, profile = make_scene(args.workload)
@@ -310,7 +317,7 @@ def main():
     c = renderer.statistics()
     counted = np.array([c["extend_rays"] + c["shadow_rays"], c["nodes"], c["triangles"]], dtype=np.float64)
     if world > 1:
-        t = torch.from_numpy(counted).cuda()
+        t = torch.from_numpy(counted).to(wire)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         counted = t.cpu().numpy()
     counted_rays = max(counted[0], 1.0)
@@ -372,10 +379,10 @@ def main():
     staged_rays = float(staged["extend_rays"] + staged["shadow_rays"])
     per_rank = [rays]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device=wire)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [float(e[0].item()) for e in every]
