@@ -332,8 +332,8 @@ rt_status rt_wavefront_set_bucket_bitmap(rt_wavefront* wavefront, const uint32_t
  * lightCount lights takes (8-byte aligned). */
 rt_status rt_light_index_bytes(uint32_t lightCount, size_t* bytes);
 /* Builds the index of `lights` (device, the array rt_launch_params.lights
- * points at) into `index`.  Waits for the stream once (the weights are
- * checked first). */
+ * points at) into `index`.  Set-up work: the stream is waited for, the index is
+ * complete when the call returns. */
 rt_status rt_light_index_build(const rt_gpu_light* lights, uint32_t lightCount, void* index, size_t indexBytes,
                                void* stream);
 /* The index of the light list the launch parameters of later rt_render_sample*

@@ -178,6 +178,8 @@ rt_status rt_light_index_build(const rt_gpu_light* lights, uint32_t lightCount, 
                            reinterpret_cast<float*>(words + 4));
         RT_HIP(hipGetLastError());
     }
+    // set-up work: the index is complete when the call returns, whatever stream reads it next
+    RT_HIP(hipStreamSynchronize(s));
     return RT_SUCCESS;
 }
 
