@@ -171,6 +171,43 @@ def test_node_hierarchy_trs_quantized_and_generated_indices(R, tmp_path):
     assert camera["aperture"] == 0.0 and camera["focusDistance"] == 10.0  # the extras' defaults
 
 
+def test_published_minimal_document(R, tmp_path):
+    """A document this repository's writer did not make: the minimal file of the Khronos glTF tutorial
+    (one triangle, 16-bit indices and positions in one embedded base64 buffer of 44 bytes), typed in as published.
+    What must come out is known from the tutorial's own text: indices 0 1 2, corners (0,0,0) (1,0,0) (0,1,0), one
+    node without a transform, no material (so the loader's default material 0), no camera, no light."""
+    text = """{
+  "scene": 0,
+  "scenes" : [ { "nodes" : [ 0 ] } ],
+  "nodes" : [ { "mesh" : 0 } ],
+  "meshes" : [ { "primitives" : [ { "attributes" : { "POSITION" : 1 }, "indices" : 0 } ] } ],
+  "buffers" : [ {
+      "uri" : "data:application/octet-stream;base64,AAABAAIAAAAAAAAAAAAAAAAAAAAAAIA/AAAAAAAAAAAAAAAAAACAPwAAAAA=",
+      "byteLength" : 44 } ],
+  "bufferViews" : [
+    { "buffer" : 0, "byteOffset" : 0, "byteLength" : 6, "target" : 34963 },
+    { "buffer" : 0, "byteOffset" : 8, "byteLength" : 36, "target" : 34962 } ],
+  "accessors" : [
+    { "bufferView" : 0, "byteOffset" : 0, "componentType" : 5123, "count" : 3, "type" : "SCALAR",
+      "max" : [ 2 ], "min" : [ 0 ] },
+    { "bufferView" : 1, "byteOffset" : 0, "componentType" : 5126, "count" : 3, "type" : "VEC3",
+      "max" : [ 1.0, 1.0, 0.0 ], "min" : [ 0.0, 0.0, 0.0 ] } ],
+  "asset" : { "version" : "2.0" }
+}"""
+    path = tmp_path / "triangle.gltf"
+    path.write_text(text)
+    loaded = R.load_scene(path)
+    counts = loaded.counts()
+    assert counts["geometries"] == 1 and counts["instances"] == 1
+    assert counts["materials"] == 1 and counts["cameras"] == 0 and counts["lights"] == 0
+    mesh = loaded.geometry(0)
+    assert np.array_equal(mesh["indices"], np.array([[0, 1, 2]], dtype=np.uint32))
+    assert np.array_equal(mesh["vertices"][:, 0:3], np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32))
+    assert mesh["material"] == 0
+    geometry, matrix = loaded.instance(0)
+    assert geometry == 0 and np.array_equal(matrix.reshape(4, 4), np.eye(4, dtype=np.float32))
+
+
 def test_light_units_and_scene_extras(R, tmp_path):
     """Punctual intensities are divided by the luminous efficacy (683 unless the scene overrides it)."""
     scene = workloads.cornell_box()
