@@ -8,5 +8,5 @@ for f in traverse wavefront; do
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include -I. $2 -c $f.hip -o /tmp/variant_$1/$f.o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -o ../lab/librt_engine_$1.so bvh_build.o core.o photon_grid.o /tmp/variant_$1/traverse.o /tmp/variant_$1/wavefront.o
+hipcc --offload-arch=gfx950 -shared -o ../lab/librt_engine_$1.so bvh_build.o core.o photon_grid.o light_index.o /tmp/variant_$1/traverse.o /tmp/variant_$1/wavefront.o
 echo built $1
