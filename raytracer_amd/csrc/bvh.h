@@ -79,9 +79,9 @@ struct Aabb {
 namespace rt {
 // Entries the traversal stack holds per lane (the first ones in LDS, the rest in private memory).
 constexpr uint32_t kTraversalStackEntries = 128;
-// Every visited node leaves at most kWide - 1 entries behind, plus one marker per
-// instance entered; a tree deeper than this would overflow the stack, and entries
-// that do not fit are dropped, i.e. hits would be missed without any error.
+// Every visited node leaves at most kWide - 1 entries behind (two entries of slack on top); a tree
+// deeper than this would overflow the stack, and entries that do not fit are dropped, i.e. hits
+// would be missed without any error.
 inline bool fitsTraversalStack(uint32_t topDepth, uint32_t bottomDepth) {
     return static_cast<uint64_t>(kWide - 1) * (static_cast<uint64_t>(topDepth) + bottomDepth) + 2U <= kTraversalStackEntries;
 }

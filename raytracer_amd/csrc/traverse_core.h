@@ -76,7 +76,6 @@ constexpr int kPrivateStack = 128 - kLdsStack;  // overflow entries per lane in 
 constexpr int kMaxStack = kLdsStack + kPrivateStack;
 static_assert(kMaxStack == static_cast<int>(kTraversalStackEntries), "fitsTraversalStack() assumes this stack size");
 constexpr uint32_t kLeafBit = 0x80000000U;
-constexpr uint32_t kSentinel = 0x7fffffffU;  // marks the return from an instance
 
 struct Ray {
     float ox, oy, oz;
@@ -261,7 +260,11 @@ struct Traversal {
     const WideNode* nodes;
     const PackedTriangle* triangles;
     uint32_t instanceId;
-    bool inBottom, found, anyHit;
+    bool found, anyHit;
+    // Stack height at which the ray entered the instance it is in, -1 while it is in the top level: entries
+    // below it belong to the top level, so taking one of them off means the instance is behind the ray.
+    int floor;
+    __device__ __forceinline__ bool inBottom() const { return floor >= 0; }
     float tmin, tminShrunk, tmax;
     float bestT, bestU, bestV;
     uint32_t bestPrim, bestInst;
@@ -300,8 +303,8 @@ struct Traversal {
                                          uint32_t instanceCount, LdsUint refs, LdsFloat ts, int s,
                                          uint32_t (&spillRef)[kPrivateStack], float (&spillT)[kPrivateStack])
         : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, idx(0.0f),
-          idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), inBottom(false), found(false),
-          anyHit(false), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
+          idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), found(false),
+          anyHit(false), floor(-1), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
           bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
           topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
 
@@ -319,7 +322,7 @@ struct Traversal {
         nodeLimit = topNodeLimit;
         itemLimit = instanceLimit;
         instanceId = kNoHit;
-        inBottom = false;
+        floor = -1;
         found = false;
         tmin = rayTmin;
         tminShrunk = rayTmin * kShrink;
@@ -355,14 +358,25 @@ struct Traversal {
     }
 
     // Takes one entry off the stack: the reference to go to, kPop when the entry
-    // needs no visit (it fell behind the closest hit, or it marked the end of an
-    // instance, which restores the world-space ray) or kDone when nothing is left.
+    // needs no visit (it fell behind the closest hit) or kDone when nothing is left.
+    // An entry from below the height at which the ray entered its instance is a
+    // top-level one: the ray goes back to world space with it.
     // One entry per call: a loop here would hold the wave's other lanes up.
     __device__ __forceinline__ uint32_t pop() {
         RT_SITE(2);
         if (sp == 0)
             return kDone;
         --sp;
+        if (sp < floor) {
+            cur = world;
+            idx = __builtin_amdgcn_rcpf(cur.dx);
+            idy = __builtin_amdgcn_rcpf(cur.dy);
+            idz = __builtin_amdgcn_rcpf(cur.dz);
+            nodes = topNodes;
+            nodeLimit = topNodeLimit;
+            itemLimit = instanceLimit;
+            floor = -1;
+        }
         const uint32_t otherwise = sp == 0 ? kDone : kPop;
         if (sp >= kMaxStack)
             return otherwise;  // never pushed (guarded against on the host as well)
@@ -374,17 +388,6 @@ struct Traversal {
         } else {
             ref = privateRef[sp - kLdsStack];
             t = privateT[sp - kLdsStack];
-        }
-        if (ref == kSentinel) {
-            cur = world;
-            idx = __builtin_amdgcn_rcpf(cur.dx);
-            idy = __builtin_amdgcn_rcpf(cur.dy);
-            idz = __builtin_amdgcn_rcpf(cur.dz);
-            nodes = topNodes;
-            nodeLimit = topNodeLimit;
-            itemLimit = instanceLimit;
-            inBottom = false;
-            return otherwise;
         }
         return t > bestT * kGrow ? otherwise : ref;
     }
@@ -539,7 +542,7 @@ struct Traversal {
         const float4 r0 = make_float4(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w));
         const float4 r1 = make_float4(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w));
         const float4 r2 = make_float4(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w));
-        push(kSentinel, 0.0f);
+        floor = sp;
         cur.ox = ((r0.x * world.ox + r0.y * world.oy) + r0.z * world.oz) + r0.w;
         cur.oy = ((r1.x * world.ox + r1.y * world.oy) + r1.z * world.oz) + r1.w;
         cur.oz = ((r2.x * world.ox + r2.y * world.oy) + r2.z * world.oz) + r2.w;
@@ -555,14 +558,13 @@ struct Traversal {
         instanceId = q4.x;
         nodeLimit = q4.z;
         itemLimit = q4.w;
-        inBottom = true;
         node = 0;
     }
 
     // Shared leaf phase, owner side: whether this lane stands at a bottom-level leaf whose triangles
     // are all inside the triangle array (a leaf that is not ends the ray, as triangleStep would).
     __device__ __forceinline__ bool atTriangles() {
-        if (!((node & kLeafBit) && node < kPop && inBottom))
+        if (!((node & kLeafBit) && node < kPop && inBottom()))
             return false;
         const uint32_t count = (node >> 28) & 7U, first = node & 0x0fffffffU;
         if (first + count > itemLimit || count == 0U) {
@@ -843,7 +845,7 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             if (walk.node == kPop)
                 walk.node = walk.pop();
             if ((walk.node & kLeafBit) && walk.node < kPop) {
-                if (!walk.inBottom) {
+                if (!walk.inBottom()) {
                     walk.enterInstance();
                 }
 #if !RT_TRACE_SHARED_LEAVES
