@@ -26,6 +26,10 @@ constexpr uint32_t kNoHit = 0xffffffffU;
 //   imask bit i clear: meta[i] >> 5 = item count (0 = empty slot),
 //                      meta[i] & 31 = first item relative to primBase
 //   items are triangles in a bottom-level tree, instances in the top level.
+//   An empty slot carries the inverted box qlo = 255, qhi = 0 on every axis, which the slab test of the
+//   traversal never enters, so the test needs no look at the slot's meta byte.  (Where the node is so
+//   small against its distance from the ray that 255 steps vanish in the rounding of the plane distances,
+//   the slot can pass the test; its reference then is a leaf of no items, which the walk drops.)
 struct alignas(16) WideNode {
     float origin[3];
     uint8_t exp[3];

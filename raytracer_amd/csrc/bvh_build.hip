@@ -693,6 +693,12 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
             triSlot += children[k].count;
         }
     }
+    // empty slots: a box no ray enters (see WideNode)
+    for (int k = count; k < kWide; ++k)
+        for (int a = 0; a < 3; ++a) {
+            node.qlo[a][k] = 255;
+            node.qhi[a][k] = 0;
+        }
     nodes[levelNodeBase + e] = node;
 }
 
@@ -1401,6 +1407,11 @@ struct TopBuilder {
                 ++itemSlot;
             }
         }
+        for (size_t k = groups.size(); k < static_cast<size_t>(kWide); ++k)  // empty slots: a box no ray enters
+            for (int a = 0; a < 3; ++a) {
+                node.qlo[a][k] = 255;
+                node.qhi[a][k] = 0;
+            }
         nodes[self] = node;
         for (auto& p : pending)
             build(p.first, p.second, level + 1);

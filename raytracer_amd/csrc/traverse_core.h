@@ -400,8 +400,8 @@ struct Traversal {
         if (COUNT)
             ++counters.nodes;
         GlobalUint4 np = globalView(nodes + node);
-        const uint4 n0 = np[0], n2 = np[2], n3 = np[3], n4 = np[4];
-        uint4 n1 = np[1];
+        const uint4 n0 = np[0];
+        uint4 n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
         uint32_t imask = n0.w >> 24;
         // A ray parallel to an axis (a direction component of exactly zero) is unconstrained on that axis
         // below: its plane distances are 0 * inf or inf - inf, the NaN that fmaxf / fminf drop.  That is
@@ -430,14 +430,18 @@ struct Traversal {
             const uint32_t outside = outsideSlab(cur.dx, cur.ox, n0.x, n0.w, n2.x, n2.y, n3.z, n3.w) |
                                      outsideSlab(cur.dy, cur.oy, n0.y, n0.w >> 8, n2.z, n2.w, n4.x, n4.y) |
                                      outsideSlab(cur.dz, cur.oz, n0.z, n0.w >> 16, n3.x, n3.y, n4.z, n4.w);
-            // a child that is dropped is struck from the node: no inner bit, no triangle count
+            // a child that is dropped is struck from the node: no inner bit, no triangle count, and the
+            // inverted box of an empty slot on every axis
             auto bytesOf = [](uint32_t four) -> uint32_t {
                 return ((four & 1U) ? 0xffU : 0U) | ((four & 2U) ? 0xff00U : 0U) | ((four & 4U) ? 0xff0000U : 0U) |
                        ((four & 8U) ? 0xff000000U : 0U);
             };
+            const uint32_t b0 = bytesOf(outside & 15U), b1 = bytesOf(outside >> 4);
             imask &= ~outside;
-            n1.z &= ~bytesOf(outside & 15U);
-            n1.w &= ~bytesOf(outside >> 4);
+            n1.z &= ~b0;
+            n1.w &= ~b1;
+            n2.x |= b0; n2.y |= b1; n2.z |= b0; n2.w |= b1; n3.x |= b0; n3.y |= b1;
+            n3.z &= ~b0; n3.w &= ~b1; n4.x &= ~b0; n4.y &= ~b1; n4.z &= ~b0; n4.w &= ~b1;
         }
         // child plane distance = q * a + b per axis; the near planes are shrunk
         // and the far planes grown by 2^-20 relative, so rounding never rejects
@@ -479,9 +483,8 @@ struct Traversal {
             // is parallel to), which leaves that axis unconstrained
             const float tn = fmaxf(fmaxf(fmaf(qxn, axn, bxn), fmaf(qyn, ayn, byn)), fmaxf(fmaf(qzn, azn, bzn), tminShrunk));
             const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
-            const uint32_t meta = ((i < 4 ? n1.z : n1.w) >> sh) & 0xffU;
-            const bool present = ((imask >> i) & 1U) || (meta >> 5) != 0U;
-            const bool hit = present && tn <= tf;
+            // an empty slot needs no test of its own: its box is inverted (see WideNode)
+            const bool hit = tn <= tf;
             key[i] = hit ? ((__float_as_uint(tn) & ~7U) | static_cast<uint32_t>(i)) : 0xffffffffU;
             hitMask |= hit ? (1U << i) : 0U;
         }
@@ -844,6 +847,8 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
 #endif
             if (walk.node == kPop)
                 walk.node = walk.pop();
+            if ((walk.node & 0xf0000000U) == kLeafBit)
+                walk.node = kPop;  // a leaf of no items: an empty slot that passed the slab test
             if ((walk.node & kLeafBit) && walk.node < kPop) {
                 if (!walk.inBottom()) {
                     walk.enterInstance();

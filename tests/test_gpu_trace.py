@@ -398,3 +398,33 @@ def test_axis_parallel_rays_stay_cheap(engine, oracle):
     parallel, ordinary = visits((o, d)), visits(oblique)
     print(f"nodes per ray: axis-parallel {parallel:.1f}, oblique {ordinary:.1f}")
     assert parallel < 1.5 * ordinary
+
+
+def test_small_mesh_seen_from_far_away(engine, oracle):
+    """A mesh whose nodes are many orders of magnitude smaller than their distance from the ray origins,
+    both as it is and behind an instance that scales it down further: the plane distances of a node's
+    children then differ by less than their rounding, the empty slots of a node (an inverted box that the
+    slab test is meant to reject) can pass the test, and the walk has to drop their references instead of
+    following them.  Hits as the oracle's, bit for bit, from every distance."""
+    soup = workloads.triangle_soup(3000, seed=21)
+    g = soup["geometries"][0]
+    g["vertices"] = g["vertices"].copy()
+    g["vertices"][:, :3] *= np.float32(1e-3)            # the mesh fills a cube of one millimetre
+    shrink = np.eye(4, dtype=np.float32)
+    shrink[0, 0] = shrink[1, 1] = shrink[2, 2] = 1e-3
+    shrink[:3, 3] = [5e-3, 0.0, 0.0]
+    scene = dict(soup)
+    scene["instances"] = [(0, np.eye(4, dtype=np.float32).reshape(-1)), (0, shrink.T.reshape(-1))]
+    rng = np.random.default_rng(22)
+    n = 40000
+    targets = rng.random((n, 3)) * 1e-3
+    targets[n // 2:] = targets[n // 2:] * 1e-3 + [5e-3, 0.0, 0.0]
+    away = rng.normal(size=(n, 3))
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    distance = 10.0 ** rng.uniform(-1.0, 7.0, (n, 1))   # ten centimetres to ten thousand kilometres
+    o = targets + away * distance
+    d = -away
+    org = np.concatenate([o, np.full((n, 1), 0.001)], axis=1).astype(np.float32)
+    dr = np.concatenate([d, np.full((n, 1), 1e16)], axis=1).astype(np.float32)
+    _, (tuv, prim, _) = check_scene(engine, oracle, scene, (org, dr))
+    assert (prim != 0xffffffff).sum() > 1000             # near origins resolve the mesh, far ones mostly do not
