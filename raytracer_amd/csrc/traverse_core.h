@@ -69,7 +69,7 @@ namespace rt {
 
 constexpr int kTraceBlock = 256;
 #ifndef RT_TRACE_LDS_STACK
-#define RT_TRACE_LDS_STACK 12
+#define RT_TRACE_LDS_STACK 15
 #endif
 constexpr int kLdsStack = RT_TRACE_LDS_STACK;  // entries per lane kept in LDS
 constexpr int kPrivateStack = 128 - kLdsStack;  // overflow entries per lane in private memory
