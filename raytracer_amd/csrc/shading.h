@@ -57,24 +57,49 @@ __device__ inline float srgbToLinear(float value) {
     return value <= 0.04045f ? value / 12.92f : powf((value + 0.055f) / 1.055f, 2.4f);
 }
 
-// device.cu:86-98 (glTF wrap modes: 33071 clamp, 33648 mirror, otherwise repeat)
-__device__ inline int wrapCoordinate(int value, uint32_t size, uint32_t mode) {
+// value mod n for n > 0 as ((value % n) + n) % n gives it, with one division instead of two, and none for a
+// power of two (the low bits of a two's complement number are its residue, negative or not).
+__device__ inline int floorMod(int value, int n) {
+    if ((n & (n - 1)) == 0)
+        return value & (n - 1);
+    const uint32_t un = static_cast<uint32_t>(n);
+    return static_cast<int>(value >= 0 ? static_cast<uint32_t>(value) % un
+                                       : un - 1U - static_cast<uint32_t>(~value) % un);
+}
+
+// device.cu:86-98 (glTF wrap modes: 33071 clamp, 33648 mirror, otherwise repeat) for a texel and its upper
+// neighbour together: the neighbour of a wrapped coordinate follows from it without another division.
+__device__ inline void wrapCoordinates(int value, uint32_t size, uint32_t mode, int& at, int& next) {
     const int n = static_cast<int>(size);
-    if (mode == 33071U)
-        return min(max(value, 0), n - 1);
-    if (mode == 33648U) {
+    if (mode == 33071U) {
+        at = min(max(value, 0), n - 1);
+        next = min(max(value + 1, 0), n - 1);
+    } else if (mode == 33648U) {
         const int period = n * 2;
-        const int coordinate = (value % period + period) % period;
-        return coordinate < n ? coordinate : period - coordinate - 1;
+        const int first = floorMod(value, period);
+        const int second = first + 1 == period ? 0 : first + 1;
+        at = first < n ? first : period - first - 1;
+        next = second < n ? second : period - second - 1;
+    } else {
+        at = floorMod(value, n);
+        next = at + 1 == n ? 0 : at + 1;
     }
-    return (value % n + n) % n;
+}
+
+// byte / 255.0f, correctly rounded, without the division: a product with the rounded reciprocal, its
+// remainder and one correction, every step one IEEE operation.  Equal to the quotient for each of the 256
+// bytes (tests/test_abi.py evaluates both in exact arithmetic).
+constexpr float kInverse255 = 1.0f / 255.0f;
+__device__ inline float unitOfByte(uint8_t byte) {
+    const float value = static_cast<float>(byte);
+    const float q = value * kInverse255;
+    return fmaf(fmaf(-q, 255.0f, value), kInverse255, q);
 }
 
 // device.cu:100-107
 __device__ inline float4 fetchTexel(const rt_gpu_texture& texture, int x, int y) {
-    const rt_uchar4 value = texture.pixels[wrapCoordinate(y, texture.height, texture.wrapV) * texture.width +
-                                           wrapCoordinate(x, texture.width, texture.wrapU)];
-    return make_float4(value.x / 255.0f, value.y / 255.0f, value.z / 255.0f, value.w / 255.0f);
+    const rt_uchar4 value = texture.pixels[y * texture.width + x];  // wrapped coordinates
+    return make_float4(unitOfByte(value.x), unitOfByte(value.y), unitOfByte(value.z), unitOfByte(value.w));
 }
 
 // device.cu:109-147: bilinear lookup through the KHR_texture_transform of the reference
@@ -85,8 +110,10 @@ __device__ inline float4 sampleTexture(const rt_gpu_texture* textures, const rt_
     const rt_gpu_texture source = textures[reference.texture];
     const rt_float2 input = reference.texCoord == 1U ? hit.uv1 : hit.uv;
     const float sx = input.x * reference.scale.x, sy = input.y * reference.scale.y;
-    const float cosine = cosf(reference.rotation);
-    const float sine = sinf(reference.rotation);
+    // a rotation of zero (either sign) has the cosine 1 and itself as its sine, exactly
+    const bool unrotated = reference.rotation == 0.0f;
+    const float cosine = unrotated ? 1.0f : cosf(reference.rotation);
+    const float sine = unrotated ? reference.rotation : sinf(reference.rotation);
     const float u = reference.offset.x + cosine * sx - sine * sy;
     const float v = reference.offset.y + sine * sx + cosine * sy;
     const float x = u * source.width - 0.5f;
@@ -95,10 +122,13 @@ __device__ inline float4 sampleTexture(const rt_gpu_texture* textures, const rt_
     const int y0 = static_cast<int>(floorf(y));
     const float tx = x - floorf(x);
     const float ty = y - floorf(y);
-    const float4 a = fetchTexel(source, x0, y0);
-    const float4 b = fetchTexel(source, x0 + 1, y0);
-    const float4 c = fetchTexel(source, x0, y0 + 1);
-    const float4 d = fetchTexel(source, x0 + 1, y0 + 1);
+    int xa, xb, ya, yb;
+    wrapCoordinates(x0, source.width, source.wrapU, xa, xb);
+    wrapCoordinates(y0, source.height, source.wrapV, ya, yb);
+    const float4 a = fetchTexel(source, xa, ya);
+    const float4 b = fetchTexel(source, xb, ya);
+    const float4 c = fetchTexel(source, xa, yb);
+    const float4 d = fetchTexel(source, xb, yb);
     float4 value = make_float4((a.x * (1.0f - tx) + b.x * tx) * (1.0f - ty) + (c.x * (1.0f - tx) + d.x * tx) * ty,
                                (a.y * (1.0f - tx) + b.y * tx) * (1.0f - ty) + (c.y * (1.0f - tx) + d.y * tx) * ty,
                                (a.z * (1.0f - tx) + b.z * tx) * (1.0f - ty) + (c.z * (1.0f - tx) + d.z * tx) * ty,
@@ -168,8 +198,7 @@ __device__ inline void environmentCoordinates(const rt_launch_params& p, V3 dire
 }
 
 __device__ inline V3 environmentPixel(const rt_launch_params& p, int x, int y) {
-    const int w = static_cast<int>(p.environmentWidth);
-    x = (x % w + w) % w;
+    x = floorMod(x, static_cast<int>(p.environmentWidth));
     y = min(max(y, 0), static_cast<int>(p.environmentHeight) - 1);
     return rgb(p.environment[y * p.environmentWidth + x]);
 }

@@ -51,3 +51,36 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(base, f)
+
+
+def test_byte_over_255_without_the_division():
+    """The texel fetch of the engine turns a byte into byte / 255.0f by q = byte * r, q + fma(-q, 255, byte) * r
+    with r = 1.0f / 255.0f (raytracer_amd/csrc/shading.h, unitOfByte): evaluated here in exact arithmetic with
+    one rounding to binary32 per operation, it equals the correctly rounded quotient for every byte."""
+    from fractions import Fraction
+
+    import numpy as np
+
+    def rn32(x):  # round to nearest binary32, ties to even (normal range is all that occurs here)
+        if x == 0:
+            return Fraction(0)
+        sign, x = (-1, -x) if x < 0 else (1, x)
+        e = x.numerator.bit_length() - x.denominator.bit_length()
+        if Fraction(2) ** e > x:
+            e -= 1
+        scaled = x / Fraction(2) ** (e - 23)          # in [2^23, 2^24)
+        lower = scaled.numerator // scaled.denominator
+        rest = scaled - lower
+        if rest > Fraction(1, 2) or (rest == Fraction(1, 2) and lower % 2 == 1):
+            lower += 1
+        return sign * lower * Fraction(2) ** (e - 23)
+
+    r = rn32(Fraction(1, 255))
+    assert float(r) == float(np.float32(1.0) / np.float32(255.0))
+    for byte in range(256):
+        v = Fraction(byte)
+        q = rn32(v * r)
+        remainder = rn32(-q * 255 + v)
+        formula = rn32(remainder * r + q)
+        assert formula == rn32(v / 255), byte
+        assert float(formula) == float(np.float32(byte) / np.float32(255.0)), byte
