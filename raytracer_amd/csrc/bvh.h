@@ -17,7 +17,11 @@ constexpr int kWide = 8;          // children per node
 constexpr int kFeedStride = 32;   // words between the per-XCD cursors of a persistent ray feed
 constexpr int kFeedWords = 8 * kFeedStride;
 constexpr int kFeedSlots = 16;    // cursor sets a scene keeps for overlapping batched queries
-constexpr int kMaxLeaf = 4;       // triangles per leaf child
+#ifndef RT_MAX_LEAF
+#define RT_MAX_LEAF 2
+#endif
+constexpr int kMaxLeaf = RT_MAX_LEAF;  // triangles per leaf child (the count field of a meta byte holds up to 7,
+                                         // the offset field 31: eight leaves of four)
 constexpr uint32_t kNoHit = 0xffffffffU;
 
 // 80 bytes, five 16-byte loads per visit.

@@ -38,7 +38,7 @@ namespace rt {
 #endif
 // Persistent launches: how many idle lanes make a wave fetch new rays.
 #ifndef RT_TRACE_REFILL
-#define RT_TRACE_REFILL 24
+#define RT_TRACE_REFILL 16
 #endif
 // Triangles a lane may test per turn.
 #ifndef RT_TRACE_LEAF_STEPS
