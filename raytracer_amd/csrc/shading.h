@@ -547,12 +547,14 @@ __device__ inline bool dielectricEvent(const rt_gpu_material& m, const rt_hit& h
 // The closest-hit program, device.cu:1081-1145: attribute interpolation at
 // (t, u, v) of triangle `primitive` of instance `instance`.  The object->world
 // normal transform multiplies by the transpose of the world->object 3x3, the
-// tangent by the object->world 3x3, each row as (a*x + b*y) + c*z.
-__device__ inline void reconstructHit(const ShadeInstance* instances, const rt_hit_group_data* geometries, V3 origin,
-                                      V3 ray, float t, float bx, float by, uint32_t primitive, uint32_t instance,
-                                      rt_hit& hit) {
+// tangent by the object->world 3x3, each row as (a*x + b*y) + c*z.  The tangent has one reader, the normal
+// map (shadingNormal): for a material without one it is left at zero and its arithmetic is not done.
+__device__ inline void reconstructHit(const ShadeInstance* instances, const rt_hit_group_data* geometries,
+                                      const rt_gpu_material* materials, V3 origin, V3 ray, float t, float bx, float by,
+                                      uint32_t primitive, uint32_t instance, rt_hit& hit) {
     const ShadeInstance& record = instances[instance];
     const rt_hit_group_data geometry = geometries[record.geometry];
+    const bool wantsTangent = materials[geometry.material].normalTexture.texture >= 0;
     const rt_uint3 triangle = geometry.indices[primitive];
     const rt_gpu_vertex v0 = geometry.vertices[triangle.x];
     const rt_gpu_vertex v1 = geometry.vertices[triangle.y];
@@ -561,33 +563,38 @@ __device__ inline void reconstructHit(const ShadeInstance* instances, const rt_h
     V3 normal = v3(v0.normal) * b0 + v3(v1.normal) * bx + v3(v2.normal) * by;
     if (dot(normal, normal) < 1e-12f)
         normal = cross(v3(v1.position) - v3(v0.position), v3(v2.position) - v3(v0.position));
-    const V3 objectNormal = normalize(normal);
+    const V3 objectNormalSum = normal;
     const float* w2o = record.toObject;
     normal = normalize(V3{(w2o[0] * normal.x + w2o[4] * normal.y) + w2o[8] * normal.z,
                           (w2o[1] * normal.x + w2o[5] * normal.y) + w2o[9] * normal.z,
                           (w2o[2] * normal.x + w2o[6] * normal.y) + w2o[10] * normal.z});
     const bool frontFace = dot(normal, ray) < 0.0f;
     const V3 facing = frontFace ? normal : -normal;
-    float tw = v0.tangent.w * b0 + v1.tangent.w * bx + v2.tangent.w * by;
-    V3 tangent{v0.tangent.x * b0 + v1.tangent.x * bx + v2.tangent.x * by,
-               v0.tangent.y * b0 + v1.tangent.y * bx + v2.tangent.y * by,
-               v0.tangent.z * b0 + v1.tangent.z * bx + v2.tangent.z * by};
-    if (dot(tangent, tangent) < 1e-12f) {
-        const float d1x = v1.uv.x - v0.uv.x, d1y = v1.uv.y - v0.uv.y;
-        const float d2x = v2.uv.x - v0.uv.x, d2y = v2.uv.y - v0.uv.y;
-        const float determinant = d1x * d2y - d1y * d2x;
-        if (fabsf(determinant) > 1e-8f)
-            tangent = ((v3(v1.position) - v3(v0.position)) * d2y - (v3(v2.position) - v3(v0.position)) * d1y) /
-                      determinant;
-        else
-            tangent = cross(fabsf(objectNormal.x) > 0.5f ? V3{0.0f, 1.0f, 0.0f} : V3{1.0f, 0.0f, 0.0f}, objectNormal);
-        tw = 1.0f;
+    float tw = 1.0f;
+    V3 tangent{0.0f, 0.0f, 0.0f};
+    if (wantsTangent) {
+        tw = v0.tangent.w * b0 + v1.tangent.w * bx + v2.tangent.w * by;
+        tangent = V3{v0.tangent.x * b0 + v1.tangent.x * bx + v2.tangent.x * by,
+                     v0.tangent.y * b0 + v1.tangent.y * bx + v2.tangent.y * by,
+                     v0.tangent.z * b0 + v1.tangent.z * bx + v2.tangent.z * by};
+        if (dot(tangent, tangent) < 1e-12f) {
+            const V3 objectNormal = normalize(objectNormalSum);
+            const float d1x = v1.uv.x - v0.uv.x, d1y = v1.uv.y - v0.uv.y;
+            const float d2x = v2.uv.x - v0.uv.x, d2y = v2.uv.y - v0.uv.y;
+            const float determinant = d1x * d2y - d1y * d2x;
+            if (fabsf(determinant) > 1e-8f)
+                tangent = ((v3(v1.position) - v3(v0.position)) * d2y - (v3(v2.position) - v3(v0.position)) * d1y) /
+                          determinant;
+            else
+                tangent = cross(fabsf(objectNormal.x) > 0.5f ? V3{0.0f, 1.0f, 0.0f} : V3{1.0f, 0.0f, 0.0f}, objectNormal);
+            tw = 1.0f;
+        }
+        const float* o2w = record.toWorld;
+        tangent = V3{(o2w[0] * tangent.x + o2w[1] * tangent.y) + o2w[2] * tangent.z,
+                     (o2w[4] * tangent.x + o2w[5] * tangent.y) + o2w[6] * tangent.z,
+                     (o2w[8] * tangent.x + o2w[9] * tangent.y) + o2w[10] * tangent.z};
+        tangent = normalize(tangent - facing * dot(tangent, facing));
     }
-    const float* o2w = record.toWorld;
-    tangent = V3{(o2w[0] * tangent.x + o2w[1] * tangent.y) + o2w[2] * tangent.z,
-                 (o2w[4] * tangent.x + o2w[5] * tangent.y) + o2w[6] * tangent.z,
-                 (o2w[8] * tangent.x + o2w[9] * tangent.y) + o2w[10] * tangent.z};
-    tangent = normalize(tangent - facing * dot(tangent, facing));
     hit.position = r3(origin + ray * t);
     hit.normal = r3(facing);
     hit.tangent.x = tangent.x;

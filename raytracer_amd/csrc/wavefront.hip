@@ -357,7 +357,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         b.sample[lobe][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     } else {
         rt_hit hit;
-        reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
+        reconstructHit(instances, geometries, p.materials, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
                        __uint_as_float(h.z), h.w, hitInstance, hit);
         const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
         const V3 normal = shadingNormal(p.textures, hit, m);
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
             int medium = static_cast<int>(flags >> 8) - 1;
             uint32_t rng = b.rng[path];
             rt_hit hit;
-            reconstructHit(instances, geometries, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
+            reconstructHit(instances, geometries, p.materials, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
                            __uint_as_float(h.z), h.w, hitInstance, hit);
             const rt_gpu_material m = applyTextures(p.textures, p.materials[hit.material], hit);
             const V3 normal = shadingNormal(p.textures, hit, m);
