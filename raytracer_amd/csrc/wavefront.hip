@@ -381,10 +381,18 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         if (medium >= 0)
             throughput = throughput * mediumAbsorption(p.materials[medium], hit.distance);
         // device.cu:943-947
-        const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, b.lightIndex, lastOrigin, hit);
-        const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
-        V3 radiance = rgb(b.sample[lobe][path]);
-        radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
+        // A surface that emits nothing adds a zero to the path's sum, whatever its weight: the sum is neither
+        // read nor written for it and the light of its triangle is not looked up.  (A zero times a throughput or
+        // a strength that is not finite would not be a zero, so those take the long way.)
+        const bool emits = m.emissive.x != 0.0f || m.emissive.y != 0.0f || m.emissive.z != 0.0f ||
+                           !isfinite((throughput.x + throughput.y + throughput.z) * m.emissiveStrength);
+        V3 radiance{0.0f, 0.0f, 0.0f};
+        if (emits) {
+            const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, b.lightIndex, lastOrigin, hit);
+            const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
+            radiance = rgb(b.sample[lobe][path]);
+            radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
+        }
 
         // next event estimation, device.cu:580-605; the visibility query is
         // deferred to the shadow stage, which adds `contribution` when the
@@ -418,7 +426,8 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
                 }
             }
         }
-        b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        if (emits)
+            b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 
         // caustic gather, device.cu:722-766, 949-950
     if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
