@@ -3,11 +3,13 @@
 # place and compares the accumulation buffers bit for bit.
 cp raytracer_amd/librt_engine.so /tmp/keep.so
 cp raytracer_amd/lab/librt_engine_base.so raytracer_amd/librt_engine.so
+export RT_ENGINE_ALLOW_MISSING=1  # the older build may lack an entry point that nothing here calls
 for s in dragon_cornell textured_sky_scene material_map_scene sphere_field; do
   timeout -k 10 120 python tools/frame_image.py /tmp/base_$s.npy $s > /dev/null 2>&1 || echo "base $s FAILED"
 done
 timeout -k 10 120 python tools/caustic_image.py /tmp/base_caustic.npy > /dev/null 2>&1
 cp /tmp/keep.so raytracer_amd/librt_engine.so
+unset RT_ENGINE_ALLOW_MISSING
 for s in dragon_cornell textured_sky_scene material_map_scene sphere_field; do
   timeout -k 10 120 python tools/frame_image.py /tmp/new_$s.npy $s > /dev/null 2>&1 || echo "new $s FAILED"
 done

@@ -3,7 +3,7 @@
 cp raytracer_amd/librt_engine.so /tmp/default_engine.so
 for f in $(ls raytracer_amd/lab/librt_engine_*.so | grep -v prof.so); do
   cp $f raytracer_amd/librt_engine.so
-  timeout -k 10 200 python bench.py --no-cpu-baseline --no-photon-bench --steps 12 $LAB_ARGS > /tmp/lab_out.json 2>/dev/null || { echo "$f FAILED"; continue; }
+  RT_ENGINE_ALLOW_MISSING=1 timeout -k 10 200 python bench.py --no-cpu-baseline --no-photon-bench --steps 12 $LAB_ARGS > /tmp/lab_out.json 2>/dev/null || { echo "$f FAILED"; continue; }
   python - "$f" <<'PY'
 import json,sys
 d=json.loads(open('/tmp/lab_out.json').read().strip().split('\n')[-1])
