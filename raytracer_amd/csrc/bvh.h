@@ -70,12 +70,18 @@ struct alignas(16) InstanceRecord {
 static_assert(sizeof(InstanceRecord) == 80, "instance record is 80 bytes");
 
 // Shading-side record of an instance, indexed by instance id.
-struct ShadeInstance {
+struct alignas(16) ShadeInstance {
     float toObject[12];
     float toWorld[12];
     uint32_t geometry;
-    uint32_t pad[3];
+    // the geometry's record (rt_scene_set_geometry), kept here as well so that a hit finds its
+    // triangle with one dependent load less
+    uint32_t material;
+    const rt_gpu_vertex* vertices;
+    const rt_uint3* indices;
+    uint32_t pad[2];
 };
+static_assert(sizeof(ShadeInstance) == 128, "shade instance is 128 bytes");
 
 struct Aabb {
     float lo[3];
@@ -116,6 +122,7 @@ struct rt_scene {
     uint64_t blasNodes = 0, blasNodeBytes = 0, triangles = 0, triangleBytes = 0;
     uint32_t blasDepth = 0;
     rt::ShadeInstance* shadeInstances = nullptr;  // indexed by instance id
+    std::vector<rt::ShadeInstance> shadeHost;     // host copy (rt_scene_set_geometry completes it)
     uint32_t shadeInstanceCount = 0;
     rt_hit_group_data* hitGroups = nullptr;       // one record per geometry (rt_scene_set_geometry)
     uint32_t hitGroupCount = 0;

@@ -1487,6 +1487,7 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     RT_HIP(hipMemcpyAsync(scene->shadeInstances, shade.data(), sizeof(ShadeInstance) * shade.size(),
                           hipMemcpyHostToDevice, stream));
     RT_HIP(hipStreamSynchronize(stream));
+    scene->shadeHost = std::move(shade);
     return RT_SUCCESS;
 }
 
@@ -1573,9 +1574,22 @@ rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* record
         RT_HIP(hipFree(scene->hitGroups));
         scene->hitGroups = nullptr;
     }
+    for (const ShadeInstance& si : scene->shadeHost)
+        if (si.geometry >= count) {
+            setLastError("an instance refers to a geometry beyond the records given");
+            return RT_ERROR_OUT_OF_RANGE;
+        }
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->hitGroups), sizeof(rt_hit_group_data) * count));
     RT_HIP(hipMemcpy(scene->hitGroups, records, sizeof(rt_hit_group_data) * count, hipMemcpyHostToDevice));
     scene->hitGroupCount = count;
+    // every instance carries its geometry's record
+    for (ShadeInstance& si : scene->shadeHost) {
+        si.material = records[si.geometry].material;
+        si.vertices = records[si.geometry].vertices;
+        si.indices = records[si.geometry].indices;
+    }
+    RT_HIP(hipMemcpy(scene->shadeInstances, scene->shadeHost.data(), sizeof(ShadeInstance) * scene->shadeHost.size(),
+                     hipMemcpyHostToDevice));
     return RT_SUCCESS;
 }
 

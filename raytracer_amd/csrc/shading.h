@@ -553,7 +553,8 @@ __device__ inline void reconstructHit(const ShadeInstance* instances, const rt_h
                                       const rt_gpu_material* materials, V3 origin, V3 ray, float t, float bx, float by,
                                       uint32_t primitive, uint32_t instance, rt_hit& hit) {
     const ShadeInstance& record = instances[instance];
-    const rt_hit_group_data geometry = geometries[record.geometry];
+    struct { const rt_gpu_vertex* vertices; const rt_uint3* indices; uint32_t material; } geometry{
+        record.vertices, record.indices, record.material};  // = geometries[record.geometry]
     const bool wantsTangent = materials[geometry.material].normalTexture.texture >= 0;
     const rt_uint3 triangle = geometry.indices[primitive];
     const rt_gpu_vertex v0 = geometry.vertices[triangle.x];

@@ -291,7 +291,7 @@ __device__ inline bool lightTriangleDistance(const ShadeInstance* instances, con
                                              uint32_t instance, uint32_t primitive, V3 origin, V3 direction, float tmin,
                                              float tmax, float& distance) {
     const ShadeInstance& record = instances[instance];
-    const rt_hit_group_data geometry = geometries[record.geometry];
+    struct { const rt_gpu_vertex* vertices; const rt_uint3* indices; } geometry{record.vertices, record.indices};
     const rt_uint3 triangle = geometry.indices[primitive];
     const rt_float3 a = geometry.vertices[triangle.x].position;
     const rt_float3 bb = geometry.vertices[triangle.y].position;
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
             // hit.  The maps of a material only scale its metallic and transmission factors down (texels
             // are at most one), so the factors alone say so, before the triangle's vertices are read.
             const uint32_t hitInstance = b.hitInstance[slot];
-            const rt_gpu_material& factors = p.materials[geometries[instances[hitInstance].geometry].material];
+            const rt_gpu_material& factors = p.materials[instances[hitInstance].material];
             const bool ends = !specularPath && !(factors.transmission > 0.0f) && !(factors.metallic > 0.5f);
             if (!ends) {
             const float4 o4 = b.rayOrigin[which][slot];
