@@ -154,7 +154,9 @@ void rt_scene_destroy(rt_scene* scene);
 /* The hit-group records of the shader binding table (src/renderer.cpp:649-660):
  * one rt_hit_group_data per geometry, indexed by rt_instance_desc.geometry.
  * `records` is host memory holding device pointers; the shading kernels read
- * vertices, indices and the material index through it. */
+ * vertices, indices and the material index through it.  The records must cover
+ * every geometry number the scene's instances carry (RT_ERROR_OUT_OF_RANGE
+ * otherwise).  Call again after changing a record. */
 rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* records, uint32_t count);
 /* The 8-byte value stored in rt_launch_params.scene (src/gpu_shared.hpp:117). */
 uint64_t rt_scene_handle(const rt_scene* scene);

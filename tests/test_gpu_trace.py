@@ -428,3 +428,18 @@ def test_small_mesh_seen_from_far_away(engine, oracle):
     dr = np.concatenate([d, np.full((n, 1), 1e16)], axis=1).astype(np.float32)
     _, (tuv, prim, _) = check_scene(engine, oracle, scene, (org, dr))
     assert (prim != 0xffffffff).sum() > 1000             # near origins resolve the mesh, far ones mostly do not
+
+
+def test_geometry_records_must_cover_every_instance(engine):
+    """The shading side looks a hit's vertices up through its instance's geometry record: a table of records
+    shorter than the geometry numbers the instances carry is refused, not read past its end."""
+    import ctypes as C
+    scene = workloads.cornell_box()
+    top, blases = engine_scene(engine, scene)
+    geometries = max(g for g, _ in scene["instances"]) + 1
+    assert geometries >= 2
+    records = (C.c_uint8 * (24 * geometries))()
+    lib = engine.load()
+    with pytest.raises(engine.EngineError, match="geometry beyond the records"):
+        engine.check(lib.rt_scene_set_geometry(top.handle, records, geometries - 1))
+    engine.check(lib.rt_scene_set_geometry(top.handle, records, geometries))
