@@ -661,33 +661,34 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
     if (pixelPath >= map.perSample)
         return;
     const uint32_t index = map.pixel(pixelPath);
-    V3 accumulated{0.0f, 0.0f, 0.0f};
+    // The running means of the pixel stay in registers over the samples of the pass: read once, written once.
+    rt_float4* const buffers[7] = {p.accumulation, p.diffuse, p.reflection, p.refraction, p.caustics, p.albedoGuide,
+                                   p.normalGuide};
+    V3 mean[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        mean[k] = rgb(buffers[k][index]);
     // the samples of a launch enter a pixel's means one after the other, in sample order
     for (uint32_t batch = 0; batch < map.samples; ++batch) {
         const uint32_t i = batch * map.perSample + pixelPath;
         const float weight = 1.0f / static_cast<float>(p.sample + batch + 1U);
         const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
         const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
-        const V3 sample = r0 + r1 + r2 + caustic;
-        auto blend = [&](rt_float4* buffer, V3 value) {
-            const V3 previous = rgb(buffer[index]);
-            const V3 next = previous + (value - previous) * weight;
-            rt_float4 out;
-            out.x = next.x;
-            out.y = next.y;
-            out.z = next.z;
-            out.w = 1.0f;
-            buffer[index] = out;
-            return next;
-        };
-        accumulated = blend(p.accumulation, sample);
-        blend(p.diffuse, r0);
-        blend(p.reflection, r1);
-        blend(p.refraction, r2);
-        blend(p.caustics, caustic);
-        blend(p.albedoGuide, albedo);
-        blend(p.normalGuide, normal);
+        const V3 value[7] = {r0 + r1 + r2 + caustic, r0, r1, r2, caustic, albedo, normal};
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            mean[k] = mean[k] + (value[k] - mean[k]) * weight;
     }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        rt_float4 out;
+        out.x = mean[k].x;
+        out.y = mean[k].y;
+        out.z = mean[k].z;
+        out.w = 1.0f;
+        buffers[k][index] = out;
+    }
+    const V3 accumulated = mean[0];
     if (p.output) {
         const V3 mapped = acesTonemap(accumulated * exp2f(p.exposure));
         rt_uchar4 out;
