@@ -55,7 +55,8 @@ struct Buffers {
     uint32_t* rng;
     float4* throughput;          // xyz + lastPdf (camera) / power xyz (photons)
     float4* lastOrigin;          // xyz + flags
-    float4* sample[6];           // radiance[0..2], caustic, albedo guide, normal guide of this sample
+    float4* sample[6];           // of this sample: [0] radiance (of the path's one lobe), [3] caustic, [4] albedo guide,
+                                 // [5] normal guide with the lobe (0-2) as the bits of .w; [1], [2] unused
     float4* gather[4];           // photon queries a shade launch leaves for the gather launch behind it:
                                  // point + path, normal, throughput, surface colour x kernel weight
     uint32_t* heavyQueries;      // photon queries that read more photons than one lane should walk
@@ -193,9 +194,13 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     b.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     b.lastOrigin[i] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kLastDelta | kPrimaryChain | kGuidePending));
     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-        b.sample[k][i] = zero;
+    // A path adds to one of the three lobe sums only (the lobe is fixed at its first hit), so one buffer
+    // holds its radiance and the lobe rides in the normal guide; the caustic sum exists with a photon map.
+    b.sample[0][i] = zero;
+    if (p.photonRadius > 0.0f)
+        b.sample[3][i] = zero;
+    b.sample[4][i] = zero;
+    b.sample[5][i] = zero;
 }
 
 // The ray stage of a bounce, one persistent launch for both kinds of ray:
@@ -259,9 +264,8 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
             const uint32_t ray = index - extendCount;
             const float4 c4 = b.shadowContribution[ray];
             const uint32_t path = b.shadowPath[ray];
-            const uint32_t lobe = __float_as_uint(c4.w) & 3U;
-            const float4 acc = b.sample[lobe][path];
-            b.sample[lobe][path] = make_float4(acc.x + c4.x, acc.y + c4.y, acc.z + c4.z, 0.0f);
+            const float4 acc = b.sample[0][path];
+            b.sample[0][path] = make_float4(acc.x + c4.x, acc.y + c4.y, acc.z + c4.z, 0.0f);
         });
     if (__ballot(walk.violations != 0U)) {
         if (walk.violations)
@@ -352,9 +356,9 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         // device.cu:910-915
         const float pdf = lastDelta ? 0.0f : environmentDensity(p, direction);
         const float weight = lastDelta ? 1.0f : powerHeuristic(lastPdf, pdf);
-        const float4 r = b.sample[lobe][path];
+        const float4 r = b.sample[0][path];
         const V3 sum = rgb(r) + throughput * environmentRadiance(p, direction) * weight;
-        b.sample[lobe][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        b.sample[0][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     } else {
         rt_hit hit;
         reconstructHit(instances, geometries, p.materials, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
@@ -367,7 +371,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
             // device.cu:920-931
             lobe = m.transmission > 0.5f ? 2U : m.metallic > 0.5f ? 1U : 0U;
             b.sample[5][path] = make_float4(dot(normal, v3(p.lensU)), dot(normal, v3(p.lensV)),
-                                            dot(normal, v3(p.cameraW)), 0.0f);
+                                            dot(normal, v3(p.cameraW)), __uint_as_float(lobe));
         }
         if (guidePending) {
             // device.cu:932-940
@@ -390,7 +394,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         if (emits) {
             const float lightPdf = lastDelta ? 0.0f : emissiveDensity(p, b.lightIndex, lastOrigin, hit);
             const float emissionWeight = lastDelta ? 1.0f : powerHeuristic(lastPdf, lightPdf);
-            radiance = rgb(b.sample[lobe][path]);
+            radiance = rgb(b.sample[0][path]);
             radiance = radiance + throughput * v3(m.emissive) * (m.emissiveStrength * emissionWeight);
         }
 
@@ -427,7 +431,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
             }
         }
         if (emits)
-            b.sample[lobe][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            b.sample[0][path] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 
         // caustic gather, device.cu:722-766, 949-950
     if (primaryChain && p.photonRadius > 0.0f && diffuseWeight > 0.0f) {
@@ -672,8 +676,15 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
     for (uint32_t batch = 0; batch < map.samples; ++batch) {
         const uint32_t i = batch * map.perSample + pixelPath;
         const float weight = 1.0f / static_cast<float>(p.sample + batch + 1U);
-        const V3 r0 = rgb(b.sample[0][i]), r1 = rgb(b.sample[1][i]), r2 = rgb(b.sample[2][i]);
-        const V3 caustic = rgb(b.sample[3][i]), albedo = rgb(b.sample[4][i]), normal = rgb(b.sample[5][i]);
+        // the path's radiance belongs to the lobe of its first hit (lobe 0 when it met nothing); the other
+        // two lobes got nothing from it
+        const float4 guide = b.sample[5][i];
+        const uint32_t lobe = __float_as_uint(guide.w) & 3U;
+        const V3 radiance = rgb(b.sample[0][i]), nothing{0.0f, 0.0f, 0.0f};
+        const V3 r0 = lobe == 0U ? radiance : nothing, r1 = lobe == 1U ? radiance : nothing,
+                 r2 = lobe == 2U ? radiance : nothing;
+        const V3 caustic = p.photonRadius > 0.0f ? rgb(b.sample[3][i]) : nothing;
+        const V3 albedo = rgb(b.sample[4][i]), normal = rgb(guide);
         const V3 value[7] = {r0 + r1 + r2 + caustic, r0, r1, r2, caustic, albedo, normal};
 #pragma unroll
         for (int k = 0; k < 7; ++k)
@@ -962,7 +973,8 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     allocate(b.throughput, maxPaths);
     allocate(b.lastOrigin, maxPaths);
     for (int k = 0; k < 6; ++k)
-        allocate(b.sample[k], maxPaths);
+        if (k != 1 && k != 2)
+            allocate(b.sample[k], maxPaths);
     for (int k = 0; k < 4; ++k)
         allocate(b.gather[k], maxPaths);
     allocate(b.heavyQueries, maxPaths);
