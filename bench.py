@@ -55,9 +55,9 @@ def parse():
     p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                    help="nccl (RCCL) for one rank per GPU; gloo rehearses the multi-rank path with several ranks on one GPU")
     p.add_argument("--batch", type=int, default=None,
-                   help="samples a wavefront pass takes (default: 1 on one GPU, 4 when several GPUs share the frame)")
-    p.add_argument("--in-flight", type=int, default=4,
-                   help="consecutive samples of a region in flight at once (each on a stream of its own)")
+                   help="samples a wavefront pass takes (default: as many as the renderer's state budget holds)")
+    p.add_argument("--in-flight", type=int, default=0,
+                   help="passes of a region in flight at once, each on a stream of its own (default 0: the renderer's choice)")
     p.add_argument("--shared", action="store_true",
                    help="run the multi-GPU code path (process group, dealt-out bands, photon exchange) with however "
                         "many ranks there are, one included: a rehearsal of the N > 1 path on one GPU")
@@ -326,6 +326,7 @@ def main():
     bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
 
     renderer.set_concurrent_tiles(args.tiles, args.in_flight)
+    in_flight = renderer.samples_in_flight()  # 0 on the command line: the renderer's own choice
     renderer.set_measurement(time_stages=False)
     for _ in range(args.warmup):
         step()
@@ -441,7 +442,7 @@ def main():
         "stage_ms_per_step": {k: v[0] / staged_steps for k, v in stages.items()},
         "trace_kernel_mrays_per_s": staged_rays / (trace_ms * 1e-3) / 1e6,
         "concurrent_tiles": args.tiles,
-        "samples_in_flight": args.in_flight,
+        "samples_in_flight": in_flight,
         "samples_per_pass": batch,
         "gather_queries_per_step": total_gathers / args.steps,
         "roofline": {

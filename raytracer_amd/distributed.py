@@ -137,7 +137,7 @@ class DistributedRenderer:
     """rt::Renderer sharded over the ranks of a process group.  Same calls as the single-GPU class:
     render(), linear_pixels(), samples()."""
 
-    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None, in_flight=4,
+    def __init__(self, scene, width, height, profile=0, group=None, photon_budget=None, tiles=None, in_flight=0,
                  batch=None):
         import torch
         import torch.distributed as dist

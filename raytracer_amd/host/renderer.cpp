@@ -431,6 +431,7 @@ struct Renderer::Impl {
     };
     std::vector<Part> parts;
     std::uint32_t partCount = 0, depth = 1;
+    std::uint32_t depthWanted = 0;  // passes in flight as asked for; 0: two, or four with a photon map (see createParts)
     // render() calls are collected into passes of up to `batch` samples (setSampleBatch; 1: every call is a
     // pass of its own): `pending` calls wait for their pass, which goes out when it is full, before a photon
     // pass, and whenever the image, the counters or the GPU are asked for.
@@ -447,7 +448,7 @@ struct Renderer::Impl {
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
     // launches leave the GPU half idle in their tails; four of them side by side fill it)
-    static constexpr std::uint32_t kDefaultParts = 1, kDefaultDepth = 4;
+    static constexpr std::uint32_t kDefaultParts = 1;
 
     ~Impl() {
         (void)hipDeviceSynchronize();
@@ -488,7 +489,7 @@ struct Renderer::Impl {
         setPhotonSizes(1U << 24U, 1U << 23U, 1U << 22U);  // renderer.cpp:533-535
         allocateFrame();
         partCount = kDefaultParts;
-        depth = kDefaultDepth;
+        depthWanted = 0;
         applyProfile(profile);
         applyCamera(scene.cameras.front());
         restart();
@@ -880,13 +881,17 @@ struct Renderer::Impl {
         destroyParts();
         const std::uint32_t count = partCount;
         partCapacity = capacity;
-        // samples per pass: what was asked for, else the most of 16, 8, 4, 2, 1 whose state fits the budget
+        // Passes in flight: what was asked for, else two - with passes of several samples a second pass is
+        // enough to cover the end of the first, and the state it saves goes into larger passes (1080p: 16 x 2
+        // 1.95 ms per sample, 8 x 4 1.99) - or four with a photon map, where a pass is one sample.
+        depth = depthWanted ? depthWanted : (caustics ? 4U : 2U);
+        // samples per pass: what was asked for, else the most of 64, 32, ..., 1 whose state fits the budget
         batch = batchWanted;
         if (batch == 0) {
             // with a photon map every fourth sample starts behind a pass that waits for the GPU, and four
             // samples in flight between two passes beat one pass over the four (3.77 against 4.42 ms per
             // sample of the 32-bounce profile, whose late bounces are launches of a few thousand rays)
-            batch = caustics ? 1U : 16U;
+            batch = caustics ? 1U : 64U;
             while (batch > 1 && capacity * count * depth * batch * kStateBytesPerPath > kStateBudget)
                 batch /= 2;
         }
@@ -1083,7 +1088,7 @@ void Renderer::stageTimings(float milliseconds[5], std::uint32_t launches[5]) {
 void Renderer::setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight) {
     impl_->dropParts();
     impl_->partCount = std::clamp<std::uint32_t>(count, 1U, 8U);
-    impl_->depth = std::clamp<std::uint32_t>(samplesInFlight, 1U, 8U);
+    impl_->depthWanted = std::min<std::uint32_t>(samplesInFlight, 8U);
     impl_->shareNumerator = impl_->shareDenominator = 0;
     impl_->restart();
 }
@@ -1112,7 +1117,9 @@ void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
 }
 
 std::uint32_t Renderer::concurrentTiles() const { return impl_->partCount; }
-std::uint32_t Renderer::samplesInFlight() const { return impl_->depth; }
+std::uint32_t Renderer::samplesInFlight() const {
+    return impl_->depthWanted ? impl_->depthWanted : (impl_->caustics ? 4U : 2U);
+}
 void Renderer::synchronize() const {
     impl_->flush();
     hipOk(hipDeviceSynchronize());

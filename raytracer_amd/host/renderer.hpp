@@ -62,14 +62,15 @@ public:
     // on a stream of its own, their accumulation steps chained in sample order: for small frames or
     // small shares of one, where a single sample's launches cannot fill the GPU.  Restarts the
     // accumulation.
-    // The default is one region with four samples in flight.
+    // samplesInFlight 0 leaves the choice to the renderer: two passes in flight, four with the final
+    // profile (whose passes are single samples).  The default is one region and that choice.
     void setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight = 1);
     std::uint32_t samplesInFlight() const;
     // render() calls are collected into passes of up to `samples` consecutive samples (1 to 64) that the GPU
     // takes in one go: the pixels' means take the samples in order as before, so the image does not change,
     // but a pass is as long as its slowest rays however few pixels it covers, and a pass over four samples
     // costs less than four passes (1080p, eight samples per pass: 2.76 -> 2.40 ms per sample; an eighth of the
-    // frame, as one of eight GPUs renders it: 0.58 -> 0.35 ms).  0, the default, takes the most of 16, 8, 4, 2, 1 samples for which
+    // frame, as one of eight GPUs renders it: 0.58 -> 0.35 ms).  0, the default, takes the most of 64, 32, 16, 8, 4, 2, 1 samples for which
     // the wavefront state (296 bytes x pixels covered x samples per pass x passes in flight) stays below
     // 24 GiB (1 with the final profile, whose photon passes cut the sequence every four samples).  A pass goes
     // out when it is full, before a photon pass, with a render() call that names a

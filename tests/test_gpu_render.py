@@ -467,7 +467,12 @@ def test_concurrent_tiles_do_not_change_the_image(R):
     w, h = 64, 72
     images = []
     default = R.Renderer(scene, w, h)
-    assert (default.concurrent_tiles(), default.samples_in_flight()) == (1, 4)
+    # the renderer's own choice: two passes in flight, four with the final profile (single-sample passes)
+    assert (default.concurrent_tiles(), default.samples_in_flight()) == (1, 2)
+    assert R.Renderer(scene, w, h, R.FINAL).samples_in_flight() == 4
+    default.set_concurrent_tiles(1, 3)
+    default.set_concurrent_tiles(1, 0)
+    assert default.samples_in_flight() == 2
     for tiles, depth in ((1, 1), (2, 1), (5, 1), (1, 4), (2, 3), (1, 8)):
         r = R.Renderer(scene, w, h)
         r.set_concurrent_tiles(tiles, depth)
