@@ -8,7 +8,6 @@ scene = workloads.dragon_cornell()
 first = None
 for share in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     r = R.Renderer(scene, 1920, 1080, 0)
-    r.set_concurrent_tiles(1, 4)
     r.set_row_interleave(0, share)
     for _ in range(64):
         r.render()
@@ -20,6 +19,6 @@ for share in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     r.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     first = first or ms
-    print(f"1/{share} of the bands, passes of {r.sample_batch()} samples: {ms:.3f} ms per sample, "
+    print(f"1/{share} of the bands, passes of {r.sample_batch()} samples, {r.samples_in_flight()} in flight: {ms:.3f} ms per sample, "
           f"efficiency {first / (ms * share):.2f}", flush=True)
     del r
