@@ -1,0 +1,43 @@
+"""GPU test of the benchmark's contract: `python bench.py` prints exactly one JSON line on stdout with the
+fields the driver reads, whatever the libraries under it print."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags):
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, capture_output=True,
+                          text=True, timeout=280)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_one_json_line_with_the_contract_fields():
+    line = run_bench("--steps", "32", "--warmup", "16", "--width", "480", "--height", "272", "--cpu-seconds", "1")
+    assert line["metric"] == "closest_hit_mrays_per_s" and line["unit"] == "Mrays/s"
+    assert line["n_gpus"] == 1 and line["steps"] == 32 and line["warmup"] == 16
+    assert line["higher_is_better"] is True and line["scaling"] == "strong" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    # value is the rays of the timed steps over their time
+    assert abs(line["value"] - line["config"]["rays_per_step"] / line["ms_per_step"] / 1e3) < 1e-6 * line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
+    assert roof["traffic"] is None          # the committed counters are of the 1080p frame
+    assert roof["copy_ceiling_gbs"] > 1000
+    # achieved = algorithmic bytes per launch over the launch time measured in this run
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "Mrays/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert cpu["gather"]["unit"] == "gathers/s" and cpu["gather"]["value"] > 0
+    assert line["photon_gathers_per_s"] > 0
