@@ -496,14 +496,13 @@ def textured_sky_scene():
                 environment=dict(pixels=sky_environment(), rotation=0.4, strength=1.2, exposure=-0.5))
 
 
-def material_map_scene(seed=11):
+def material_map_scene(seed=11, size=32, checker=64):
     """Every texture slot of a material at once: a floor with colour, normal and metallic-roughness maps
     (the normal map through the second texture coordinate set, clamped and mirrored wrap modes), an
     emissive panel whose emission comes from a striped map, and a glass ball whose transmission and
     thickness are modulated by maps; tangents and both coordinate sets are filled in."""
     rng = np.random.default_rng(seed)
-    size = 32
-    y, x = np.mgrid[0:size, 0:size]
+    y, x = np.mgrid[0:size, 0:size]  # `size`, `checker`: edge lengths of the maps (powers of two or not)
     bumps = np.stack([128 + 80 * np.sin(x * 0.8), 128 + 80 * np.cos(y * 0.6), np.full_like(x, 230.0),
                       np.full_like(x, 255.0)], -1)
     normal_map = np.ascontiguousarray(np.clip(bumps, 0, 255).astype(np.uint8))
@@ -515,7 +514,7 @@ def material_map_scene(seed=11):
     fade[..., 0] = (x * 255 // (size - 1)).astype(np.uint8)          # transmission reads red
     fade[..., 1] = (255 - y * 200 // (size - 1)).astype(np.uint8)    # thickness reads green
     fade[..., 2:] = 255
-    images = [checker_image(), normal_map, rough_metal, np.ascontiguousarray(stripes), np.ascontiguousarray(fade)]
+    images = [checker_image(size=checker), normal_map, rough_metal, np.ascontiguousarray(stripes), np.ascontiguousarray(fade)]
     textures = [dict(image=0, wrapU=33071, wrapV=33071), dict(image=1, wrapU=10497, wrapV=33648),
                 dict(image=2, wrapU=33648, wrapV=10497), dict(image=3), dict(image=4)]
 

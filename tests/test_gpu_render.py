@@ -651,6 +651,20 @@ def test_every_material_map_matches_oracle(R, oracle):
         assert changed > 0.01, (slot, changed)
 
 
+def test_texture_wrap_with_sizes_that_are_no_power_of_two(R, oracle):
+    """The same maps at edge lengths 29 and 45: repeat, mirror and clamp then go through the general residue
+    (a power of two only needs a mask), with coordinates that run below zero; first-hit buffers and image
+    against the oracle's device.cu:86-98."""
+    scene = workloads.material_map_scene(size=29, checker=45)
+    w, h = 112, 80
+    r, host, gpu, cpu = render_both(R, oracle, scene, w, h, 2)
+    assert np.isfinite(gpu).all() and cpu[:, :3].mean() > 0.01
+    assert close_fraction(gpu, cpu, rel=2e-3) > 0.97
+    for k in (5, 6):  # albedo and normal guides: what the maps say at the first hit, without path noise
+        dev = R.device_to_host(r.accumulation_buffer(k), w * h * 16).view(np.float32).reshape(-1, 4)
+        assert close_fraction(dev, host.aov[k], rel=2e-3) > 0.97, k
+
+
 def test_scene_loaded_from_gltf_renders_the_same(R, tmp_path):
     """A scene that went through the glTF writer and rt::loadScene renders bit-identically to the scene
     built directly (PNG texture and Radiance environment included; the environment is compared after the
