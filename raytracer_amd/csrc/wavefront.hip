@@ -52,9 +52,10 @@ struct Buffers {
     float4* shadowContribution;  // xyz + bits: lobe (0-1), needs the light's own triangle (2)
     uint32_t* shadowPath;
     uint2* shadowTarget;         // instance, primitive of the sampled emissive triangle
-    uint32_t* rng;
-    float4* throughput;          // xyz + lastPdf (camera) / power xyz (photons)
-    float4* lastOrigin;          // xyz + flags
+    // the state a path carries from bounce to bounce travels with its ray, in the queue's slot order
+    uint32_t* rng[2];
+    float4* throughput[2];       // xyz + lastPdf (camera) / power xyz (photons)
+    float4* lastOrigin[2];       // xyz + flags
     float4* sample[6];           // of this sample: [0] radiance (of the path's one lobe), [3] caustic, [4] albedo guide,
                                  // [5] normal guide with the lobe (0-2) as the bits of .w; [1], [2] unused
     float4* gather[4];           // photon queries a shade launch leaves for the gather launch behind it:
@@ -190,9 +191,9 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     b.rayOrigin[0][i] = make_float4(origin.x, origin.y, origin.z, 0.001f);
     b.rayDirection[0][i] = make_float4(direction.x, direction.y, direction.z, 1e16f);
     b.rayPath[0][i] = i;
-    b.rng[i] = rng;
-    b.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    b.lastOrigin[i] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kLastDelta | kPrimaryChain | kGuidePending));
+    b.rng[0][i] = rng;
+    b.throughput[0][i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    b.lastOrigin[0][i] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(kLastDelta | kPrimaryChain | kGuidePending));
     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // A path adds to one of the three lobe sums only (the lobe is fixed at its first hit), so one buffer
     // holds its radiance and the lobe rides in the normal guide; the caustic sum exists with a photon map.
@@ -324,14 +325,18 @@ struct ShadeOut {
     float shadowLimit = 0.0f;
     uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
     uint32_t gatherQueries = 0, gathered = 0;  // INLINE_GATHER only
+    // the path's state behind the bounce (written next to its next ray when it continues)
+    float4 throughputAfter{0, 0, 0, 0}, lastOriginAfter{0, 0, 0, 0};
+    uint32_t rngAfter = 0;
 };
 
 // One bounce of device.cu:908-1041 for the path whose ray (origin, direction) met the scene at `h`.
 // INLINE_GATHER: the caustic gather is done here instead of being queued.
 template <bool INLINE_GATHER>
 __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* instances,
-                                const rt_hit_group_data* geometries, const Buffers& b, uint32_t path, V3 origin,
-                                V3 direction, uint4 h, uint32_t hitInstance, uint32_t depth, ShadeOut& out) {
+                                const rt_hit_group_data* geometries, const Buffers& b, int which, uint32_t slot,
+                                uint32_t path, V3 origin, V3 direction, uint4 h, uint32_t hitInstance, uint32_t depth,
+                                ShadeOut& out) {
     bool& continues = out.continues;
     bool& wantsShadow = out.wantsShadow;
     V3& shadowOrigin = out.shadowOrigin;
@@ -341,16 +346,16 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
     uint32_t& shadowBits = out.shadowBits;
     uint32_t& targetInstance = out.targetInstance;
     uint32_t& targetPrimitive = out.targetPrimitive;
-    const float4 tp = b.throughput[path];
+    const float4 tp = b.throughput[which][slot];
     V3 throughput{tp.x, tp.y, tp.z};
     float lastPdf = tp.w;
-    const float4 lo = b.lastOrigin[path];
+    const float4 lo = b.lastOrigin[which][slot];
     const V3 lastOrigin{lo.x, lo.y, lo.z};
     uint32_t flags = __float_as_uint(lo.w);
     uint32_t lobe = flags & 3U;
     bool lastDelta = flags & kLastDelta, primaryChain = flags & kPrimaryChain, guidePending = flags & kGuidePending;
     int medium = static_cast<int>(flags >> 8) - 1;
-    uint32_t rng = b.rng[path];
+    uint32_t rng = b.rng[which][slot];
 
     if (h.w == kNoHit) {
         // device.cu:910-915
@@ -512,11 +517,11 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
         if (depth + 1U >= p.maxDepth)
             continues = false;
         if (continues) {
-            b.rng[path] = rng;
-            b.throughput[path] = make_float4(throughput.x, throughput.y, throughput.z, lastPdf);
+            out.rngAfter = rng;
+            out.throughputAfter = make_float4(throughput.x, throughput.y, throughput.z, lastPdf);
             flags = lobe | (lastDelta ? kLastDelta : 0U) | (primaryChain ? kPrimaryChain : 0U) |
                     (guidePending ? kGuidePending : 0U) | static_cast<uint32_t>(medium + 1) << 8;
-            b.lastOrigin[path] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(flags));
+            out.lastOriginAfter = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(flags));
         }
     }
     out.origin = origin;
@@ -538,8 +543,8 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
         path = b.rayPath[which][slot];
         const float4 o4 = b.rayOrigin[which][slot];
         const float4 d4 = b.rayDirection[which][slot];
-        shadeOne<false>(p, instances, geometries, b, path, V3{o4.x, o4.y, o4.z}, V3{d4.x, d4.y, d4.z}, b.hits[slot],
-                        b.hitInstance[slot], depth, out);
+        shadeOne<false>(p, instances, geometries, b, which, slot, path, V3{o4.x, o4.y, o4.z}, V3{d4.x, d4.y, d4.z},
+                        b.hits[slot], b.hitInstance[slot], depth, out);
     }
     const bool continues = out.continues, wantsShadow = out.wantsShadow;
     const V3 origin = out.origin, direction = out.direction;
@@ -554,6 +559,9 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
         b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
         b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
         b.rayPath[next][nextSlot] = path;
+        b.rng[next][nextSlot] = out.rngAfter;
+        b.throughput[next][nextSlot] = out.throughputAfter;
+        b.lastOrigin[next][nextSlot] = out.lastOriginAfter;
     }
     if (wantsShadow) {
         b.shadowOrigin[shadowSlot] = make_float4(shadowOrigin.x, shadowOrigin.y, shadowOrigin.z, 0.001f);
@@ -777,9 +785,9 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
         b.rayOrigin[0][slot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
         b.rayDirection[0][slot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
         b.rayPath[0][slot] = i;
-        b.rng[i] = rng;
-        b.throughput[i] = make_float4(power.x, power.y, power.z, 0.0f);
-        b.lastOrigin[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0U));  // flags: bit 0 specular path, medium
+        b.rng[0][slot] = rng;
+        b.throughput[0][slot] = make_float4(power.x, power.y, power.z, 0.0f);
+        b.lastOrigin[0][slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0U));  // flags: bit 0 specular path, medium
     }
 }
 
@@ -794,12 +802,13 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x;
     bool continues = false;
     V3 origin{0, 0, 0}, direction{0, 0, 0};
-    uint32_t path = 0;
+    uint32_t path = 0, rngAfter = 0, flagsAfter = 0;
+    float4 powerAfter = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (slot < n) {
         path = b.rayPath[which][slot];
         const uint4 h = b.hits[slot];
         if (h.w != kNoHit) {
-            uint32_t flags = __float_as_uint(b.lastOrigin[path].w);
+            uint32_t flags = __float_as_uint(b.lastOrigin[which][slot].w);
             bool specularPath = flags & 1U;
             // A photon that has met nothing specular yet ends, without a trace, on a surface that neither
             // transmits nor mirrors (device.cu:826-858 fall through): most photons of a pass, at their first
@@ -813,10 +822,10 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
             const float4 d4 = b.rayDirection[which][slot];
             origin = V3{o4.x, o4.y, o4.z};
             direction = V3{d4.x, d4.y, d4.z};
-            const float4 pw = b.throughput[path];
+            const float4 pw = b.throughput[which][slot];
             V3 power{pw.x, pw.y, pw.z};
             int medium = static_cast<int>(flags >> 8) - 1;
-            uint32_t rng = b.rng[path];
+            uint32_t rng = b.rng[which][slot];
             rt_hit hit;
             reconstructHit(instances, geometries, p.materials, origin, direction, __uint_as_float(h.x), __uint_as_float(h.y),
                            __uint_as_float(h.z), h.w, hitInstance, hit);
@@ -856,10 +865,9 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
             if (depth + 1U >= 10U)
                 continues = false;
             if (continues) {
-                b.rng[path] = rng;
-                b.throughput[path] = make_float4(power.x, power.y, power.z, 0.0f);
-                flags = (specularPath ? 1U : 0U) | static_cast<uint32_t>(medium + 1) << 8;
-                b.lastOrigin[path] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
+                rngAfter = rng;
+                powerAfter = make_float4(power.x, power.y, power.z, 0.0f);
+                flagsAfter = (specularPath ? 1U : 0U) | static_cast<uint32_t>(medium + 1) << 8;
             }
             }
         }
@@ -870,6 +878,9 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
         b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
         b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
         b.rayPath[next][nextSlot] = path;
+        b.rng[next][nextSlot] = rngAfter;
+        b.throughput[next][nextSlot] = powerAfter;
+        b.lastOrigin[next][nextSlot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flagsAfter));
     }
 }
 
@@ -969,9 +980,11 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     allocate(b.shadowContribution, maxPaths);
     allocate(b.shadowPath, maxPaths);
     allocate(b.shadowTarget, maxPaths);
-    allocate(b.rng, maxPaths);
-    allocate(b.throughput, maxPaths);
-    allocate(b.lastOrigin, maxPaths);
+    for (int k = 0; k < 2; ++k) {
+        allocate(b.rng[k], maxPaths);
+        allocate(b.throughput[k], maxPaths);
+        allocate(b.lastOrigin[k], maxPaths);
+    }
     for (int k = 0; k < 6; ++k)
         if (k != 1 && k != 2)
             allocate(b.sample[k], maxPaths);

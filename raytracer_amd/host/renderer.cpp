@@ -442,9 +442,9 @@ struct Renderer::Impl {
     // when that grows or shrinks to less than half: a GPU that takes one share of many has state for its share.
     std::uint64_t partCapacity = 0;                     // pixels one part has room for
     std::uint32_t shareNumerator = 0, shareDenominator = 0;  // setRayShare; 0: the policy of createParts
-    // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x 296 bytes
+    // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x 332 bytes
     static constexpr std::uint64_t kStateBudget = 24ULL << 30;
-    static constexpr std::uint64_t kStateBytesPerPath = 296;
+    static constexpr std::uint64_t kStateBytesPerPath = 332;
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
     // launches leave the GPU half idle in their tails; four of them side by side fill it)
@@ -716,7 +716,7 @@ struct Renderer::Impl {
 
     std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {  // :746-769
         // The photon pass has wavefront state of its own, sized for a whole pass (at most 2^24 paths,
-        // 296 bytes each): every batch ends with the drain of its ray launches, so few large batches
+        // 332 bytes each): every batch ends with the drain of its ray launches, so few large batches
         // beat many frame-sized ones.
         const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
         if (!photonWavefront || photonWavefrontCapacity < wanted) {

@@ -71,7 +71,7 @@ public:
     // but a pass is as long as its slowest rays however few pixels it covers, and a pass over four samples
     // costs less than four passes (1080p, eight samples per pass: 2.76 -> 2.40 ms per sample; an eighth of the
     // frame, as one of eight GPUs renders it: 0.58 -> 0.35 ms).  0, the default, takes the most of 64, 32, 16, 8, 4, 2, 1 samples for which
-    // the wavefront state (296 bytes x pixels covered x samples per pass x passes in flight) stays below
+    // the wavefront state (332 bytes x pixels covered x samples per pass x passes in flight) stays below
     // 24 GiB (1 with the final profile, whose photon passes cut the sequence every four samples).  A pass goes
     // out when it is full, before a photon pass, with a render() call that names a
     // target of the caller, and whenever the image, the counters or the GPU are asked for (pixels(),
