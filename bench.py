@@ -5,7 +5,8 @@ One "step" is one pass of the hot path over one frame of synthetic input: one ca
 pixel of the Dragon-Cornell stand-in (a ~870k-triangle absorbing-glass mesh in a Cornell box with an
 emissive panel) at 1920x1080, preview profile (5 bounces), through rt::Renderer::render(): generate,
 then per bounce trace / shade (the shadow rays of a bounce ride in the same persistent launch as the
-closest-hit rays of the next), then accumulate.  Scene, BVH and every buffer are resident in HBM
+closest-hit rays of the next), then accumulate; the renderer takes the calls in passes of several
+samples (sixteen at this size, two passes in flight; the image is the same).  Scene, BVH and every buffer are resident in HBM
 before the timed region.  The headline value is rays traced (closest-hit + shadow) per second over
 the whole step; the trace kernel's share is priced against the HBM roofline.
 
