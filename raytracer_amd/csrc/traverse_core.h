@@ -67,7 +67,10 @@ namespace rt {
 #define RT_TRACE_GRID_SCALE 1
 #endif
 
-constexpr int kTraceBlock = 256;
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = RT_TRACE_BLOCK;  // lanes of a ray-kernel workgroup (128 and 512 measured no better)
 #ifndef RT_TRACE_LDS_STACK
 #define RT_TRACE_LDS_STACK 15
 #endif
