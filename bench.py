@@ -15,7 +15,10 @@ and gathered once per step count for the second metric (photon gathers/s, grid b
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch with torch.distributed.run, one rank per GPU over RCCL: every rank holds a replica of
+For N > 1 either launch with torch.distributed.run, one rank per GPU over RCCL, or run the plain command:
+when --gpus N > 1 and the environment names no WORLD_SIZE, this process starts the N ranks itself as child
+processes (before anything here has touched the GPU), passes rank 0's JSON line on to its stdout and
+everything else to stderr, and fails when a rank fails.  Every rank holds a replica of
 the scene and the N ranks share each frame (strong scaling of one frame): the bands of eight pixel rows
 are dealt out in turn (band b to rank b mod N), so a step is still one sample of every pixel of the
 frame; in the final profile every rank traces its share of the photon emissions and the lists are
@@ -259,8 +262,59 @@ def cpu_gather_baseline(grid, qp, qn, radius, buckets, seconds):
                       f"{srt.shape[0]}-photon grid, the oracle's gather loop on {threads} std::thread workers, {cpu_s:.2f} s"}
 
 
+def launch_ranks(args):
+    """Starts args.gpus ranks of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, as torch.distributed.run would set them), relays rank 0's stdout (the one JSON line) to
+    this process's stdout and every other stream to stderr.  Returns the exit status: non-zero when any rank
+    failed; the ranks still running at that point are ended.  This process never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ranks = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ranks.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+    # rank 0 writes its line at the very end; it is read beside the watch over the ranks, so that a rank that
+    # dies early cannot leave this process waiting for a line that will never come
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.append(ranks[0].stdout.read()), daemon=True)
+    reader.start()
+    status = 0
+    while any(child.poll() is None for child in ranks):
+        for rank, child in enumerate(ranks):
+            code = child.poll()
+            if code not in (None, 0) and status == 0:
+                print(f"bench.py: rank {rank} ended with status {code}", file=sys.stderr)
+                status = code if code > 0 else 1
+                for other in ranks:   # a rank that lost a peer would wait in its next collective for ever
+                    if other.poll() is None:
+                        other.kill()
+        time.sleep(0.05)
+    for rank, child in enumerate(ranks):
+        if child.returncode != 0 and status == 0:
+            print(f"bench.py: rank {rank} ended with status {child.returncode}", file=sys.stderr)
+            status = child.returncode if child.returncode > 0 else 1
+    reader.join(timeout=10.0)
+    line = lines[0] if lines else b""
+    if status == 0 and not line.strip():
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        status = 1
+    if status == 0:
+        sys.stdout.buffer.write(line)
+        sys.stdout.flush()
+    return status
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     # Libraries under this process write to the C stdout (RCCL prints a version banner there when a
     # communicator comes up).  The one JSON line must be all that stdout carries: everything else goes to
     # stderr, and the line is written to the saved descriptor at the end.

@@ -41,3 +41,27 @@ def test_one_json_line_with_the_contract_fields():
     assert cpu["kind"] == "port" and cpu["unit"] == "Mrays/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert cpu["gather"]["unit"] == "gathers/s" and cpu["gather"]["value"] > 0
     assert line["photon_gathers_per_s"] > 0
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it starts two ranks itself (gloo here: both share the
+    one GPU of the test box) and prints the one line of a two-rank run."""
+    env_free = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                           "--steps", "16", "--warmup", "16", "--width", "480", "--height", "272",
+                           "--no-cpu-baseline", "--no-photon-bench"], cwd=ROOT, capture_output=True, text=True,
+                          timeout=280, env=env_free)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [line for line in done.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and len(line["multi_gpu"]["rays_per_rank"]) == 2
+    assert all(r > 0 for r in line["multi_gpu"]["rays_per_rank"])
+    assert abs(sum(line["multi_gpu"]["rays_per_rank"]) / 16 - line["config"]["rays_per_step"]) < 1e-6 * line["config"]["rays_per_step"]
+
+
+def test_a_failing_rank_fails_the_run():
+    """A rank that cannot start (an unknown workload reaches argparse in every rank) ends the whole run non-zero."""
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nope"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert done.returncode != 0 and not done.stdout.strip()

@@ -24,6 +24,18 @@ def test_keys_bit_exact(engine, oracle):
     assert np.array_equal(keys, oracle.photon_keys(pos, cs, B))
 
 
+def test_keys_match_the_reference_header_outputs(engine):
+    """rt_photon_keys against tests/golden/photon_hash_ref.npz, the outputs of the reference's own
+    photon_hash.cuh:10-24 (made by tests/golden/make_hash_fixture.py): three cell sizes x 2^4, 2^14, 2^22 buckets."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "photon_hash_ref.npz"))
+    for k in range(3):
+        cs, pos = float(f[f"cellSize_{k}"]), f[f"positions_{k}"]
+        for bits in (4, 14, 22):
+            keys = u32(engine.photon_keys(dev(pos), cs, 1 << bits))
+            assert np.array_equal(keys, f[f"keys_{k}_{bits}"].astype(np.uint32)), (cs, bits)
+
+
 @pytest.mark.parametrize("n,B,cs", [(1, 1 << 4, 0.01), (63, 1 << 8, 0.01), (8192, 1 << 12, 0.004),
                                      (8193, 1 << 12, 0.004), (100000, 1 << 16, 0.002), (300001, 1 << 22, 0.0015)])
 def test_grid_build_bit_exact(engine, oracle, n, B, cs):

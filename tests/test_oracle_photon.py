@@ -31,6 +31,51 @@ def test_hash_known_answers(oracle):
         assert oracle.photon_bucket(cell, kat["bucketCount"]) == v["bucket"]
 
 
+def reference_hash_fixture():
+    """(cellSize, positions, cells, {bits: keys}) per cell size of photon_hash_ref.npz: outputs of the reference's
+    own photon_hash.cuh:10-24, made by tests/golden/make_hash_fixture.py."""
+    f = np.load(os.path.join(GOLDEN, "photon_hash_ref.npz"))
+    k = 0
+    while f"positions_{k}" in f:
+        yield (float(f[f"cellSize_{k}"]), f[f"positions_{k}"], f[f"cells_{k}"],
+               {bits: f[f"keys_{k}_{bits}"].astype(np.uint32) for bits in (4, 14, 22)})
+        k += 1
+
+
+def test_hash_matches_the_reference_header_outputs(oracle):
+    """The oracle's cell and bucket of every fixture position equal what the reference's header gave."""
+    sizes = 0
+    for cs, pos, cells, keys in reference_hash_fixture():
+        assert pos.shape[0] >= 65536
+        mine = np.stack([oracle.photon_cell(p, cs) for p in pos[:: max(1, pos.shape[0] // 4096)]])
+        assert np.array_equal(mine, cells[:: max(1, pos.shape[0] // 4096)])
+        assert np.array_equal(np_cell(pos, cs), cells)           # the numpy restatement, every position
+        for bits, ref in keys.items():
+            assert np.array_equal(oracle.photon_keys(pos, cs, 1 << bits), ref), (cs, bits)
+            assert np.array_equal(np_bucket(cells, 1 << bits), ref)
+        sizes += 1
+    assert sizes == 3
+
+
+def test_reference_header_built_here_reproduces_the_fixture():
+    """Where oracle/_ref holds the reference's header compiled in this container, it gives the fixture again."""
+    import ctypes as C
+    import pytest
+    path = os.path.join(os.path.dirname(GOLDEN), os.pardir, "oracle", "_ref", "libref_hash.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref is only built where /root/reference is present")
+    lib = C.CDLL(os.path.abspath(path))
+    lib.ref_photon_hash.restype = None
+    lib.ref_photon_hash.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_uint, C.c_void_p, C.c_void_p]
+    for cs, pos, cells, keys in reference_hash_fixture():
+        got_cells = np.empty_like(cells)
+        got_keys = np.empty(pos.shape[0], dtype=np.uint32)
+        for bits, ref in keys.items():
+            lib.ref_photon_hash(pos.ctypes.data, pos.shape[0], np.float32(cs), 1 << bits, got_cells.ctypes.data,
+                                got_keys.ctypes.data)
+            assert np.array_equal(got_cells, cells) and np.array_equal(got_keys, ref)
+
+
 def test_hash_edge_cases_match_numpy(oracle):
     cs = 0.0037
     pos = workloads.hash_edge_positions(cs)
