@@ -89,3 +89,20 @@ def test_shard_ranges_tile_the_space():
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             sizes = [e - b for b, e in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_fails_when_its_ranks_fail():
+    """`bench.py --gpus 2` starts two ranks itself; without a GPU both refuse to run (the engine has no CPU
+    path), and the launcher must end non-zero with nothing on stdout instead of waiting for a result line."""
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU: there the ranks fail at once")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"],
+                          cwd=root, capture_output=True, text=True, timeout=240, env=env)
+    assert done.returncode != 0 and not done.stdout.strip()
+    assert "rank" in done.stderr and "needs a GPU" in done.stderr

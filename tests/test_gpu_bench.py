@@ -59,9 +59,3 @@ def test_gpus_flag_starts_its_own_ranks():
     assert all(r > 0 for r in line["multi_gpu"]["rays_per_rank"])
     assert abs(sum(line["multi_gpu"]["rays_per_rank"]) / 16 - line["config"]["rays_per_step"]) < 1e-6 * line["config"]["rays_per_step"]
 
-
-def test_a_failing_rank_fails_the_run():
-    """A rank that cannot start (an unknown workload reaches argparse in every rank) ends the whole run non-zero."""
-    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nope"],
-                          cwd=ROOT, capture_output=True, text=True, timeout=120)
-    assert done.returncode != 0 and not done.stdout.strip()
