@@ -67,6 +67,26 @@ rt_status rt_build_photon_grid_async(const rt_photon* photons, uint32_t count, f
                                      uint32_t* counts, uint32_t* offsets, void* scan, size_t scanBytes,
                                      rt_photon* sorted, void* stream);
 
+/* rt_build_photon_grid_async for a photon list whose length only exists in
+ * device memory: the count is min(*countOnDevice, maxCount), read by the
+ * kernels when they run, so the host neither waits for the photon tracer nor
+ * reads the counter back before it enqueues the build (the reference does both,
+ * src/renderer.cpp:753-769, and clamps the count to the capacity on the host,
+ * :769; here the clamp is the min above).  Launches are sized for maxCount;
+ * scan must hold rt_photon_grid_scratch_bytes(maxCount, bucketCount) or the
+ * library's own workspace is used.  Same offsets and sorted list as a build
+ * with the count on the host.  keysReady != 0: the caller has already written
+ * the bucket key of photon i to rt_photon_grid_keys(scan, ...)[i] for every
+ * i < count (rt_wavefront_set_photon_keys makes the photon tracer do so while
+ * it stores the photon, which saves the pass that reads every record again
+ * for its position); scan must then be the caller's. */
+rt_status rt_build_photon_grid_counted(const rt_photon* photons, const uint32_t* countOnDevice, uint32_t maxCount,
+                                       float cellSize, uint32_t bucketCount, uint32_t* offsets, void* scan,
+                                       size_t scanBytes, rt_photon* sorted, int keysReady, void* stream);
+/* Where a build over `scan` (sized for maxCount photons) expects the bucket keys of
+ * its photons: maxCount uint32 inside the scratch, or null when the scratch is too small. */
+uint32_t* rt_photon_grid_keys(void* scan, size_t scanBytes, uint32_t maxCount, uint32_t bucketCount);
+
 /* rt_build_photon_grid_async for callers that cannot allocate device memory
  * (code under HIP graph capture, serving loops, harnesses that forbid
  * hipMalloc).  No counterpart in the reference.  The sort's scratch is a
@@ -222,6 +242,17 @@ rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* origi
 typedef struct rt_wavefront rt_wavefront; /* ray queues and per-path state for up to maxPaths paths */
 rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out);
 void rt_wavefront_destroy(rt_wavefront* wavefront);
+/* A state for one kind of pass only leaves out the arrays the other kind needs
+ * (a camera pass has no use for the per-emission photon slots, a photon pass
+ * none for shadow rays, sample sums and photon queries); rt_wavefront_create
+ * is both.  rt_wavefront_state_bytes: the device memory such a state takes,
+ * from the same list of arrays the allocation walks - what a caller sizes a
+ * pass against free memory with.  No counterpart upstream (OptiX keeps the
+ * state of a launch in its own stack and registers). */
+#define RT_WAVEFRONT_FOR_CAMERA 1u  /* rt_render_sample* */
+#define RT_WAVEFRONT_FOR_PHOTONS 2u /* rt_trace_photons */
+rt_status rt_wavefront_create_for(uint32_t maxPaths, uint32_t uses, rt_wavefront** out);
+rt_status rt_wavefront_state_bytes(uint32_t maxPaths, uint32_t uses, size_t* bytes);
 
 /* One camera sample (params->sample) for the pixels [pixelBegin, pixelEnd) in
  * row-major order, row 0 at the bottom: generate, then maxDepth rounds of extend
@@ -264,6 +295,14 @@ rt_status rt_render_sample_bands(rt_wavefront* wavefront, const rt_launch_params
  * (src/renderer.cpp:743).  Enqueued on `stream`. */
 rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
                            uint32_t emissionCount, void* stream);
+
+/* Later rt_trace_photons calls on this state also write the bucket key of every
+ * photon they store - photonBucket(photonCell(position, params->photonRadius),
+ * params->photonBucketCount), src/photon_hash.cuh:10-24 - to keys[slot], slot
+ * being the photon's index in params->photons; keys holds params->photonCapacity
+ * uint32 (device).  Null (the default) switches it off.  Meant for
+ * rt_build_photon_grid_counted(keysReady = 1) with cellSize = params->photonRadius. */
+rt_status rt_wavefront_set_photon_keys(rt_wavefront* wavefront, uint32_t* keys);
 
 /* Copies the running counters to out8 (host): [0] closest-hit (extend) rays,
  * [1] shadow rays, [2] caustic gather queries, [3] photons read by them,
@@ -310,6 +349,27 @@ rt_status rt_wavefront_set_sample_batch(rt_wavefront* wavefront, uint32_t sample
  * steps of that region with these events; everything before the accumulation
  * of a sample is independent of other samples.  No counterpart upstream. */
 rt_status rt_wavefront_set_accumulate_events(rt_wavefront* wavefront, void* waitFor, void* record);
+/* The photon maps later rt_render_sample* calls on this state gather from, for
+ * passes of more samples than one map serves.  The reference traces a new map
+ * before every fourth sample (src/renderer.cpp:177, 780-781), so samples 4e ..
+ * 4e + 3 read map e; a pass over samples s0 .. s0 + n - 1 (rt_wavefront_set_
+ * sample_batch) is given the maps of the groups it covers, in order, with
+ * samplesPerMap = 4 and phase = s0 % 4, and sample s0 + k gathers from map
+ * (phase + k) / samplesPerMap - the image is that of one pass per sample with
+ * the map rebuilt in between.  All maps share params->photonBucketCount and
+ * params->photonRadius; bucketBits may be null (every range is read).  count =
+ * 0 (the default): the one map of the launch parameters and rt_wavefront_set_
+ * bucket_bitmap.  The table is copied; the maps must stay as they are until
+ * the passes that read them have finished. */
+#define RT_MAX_PHOTON_MAPS 16
+typedef struct rt_photon_map {
+    const rt_photon* sortedPhotons; /* rt_launch_params.sortedPhotons of that map */
+    const uint32_t* cellStart;      /* rt_launch_params.photonCellStart */
+    const uint32_t* bucketBits;     /* rt_photon_bucket_bitmap of it, or null */
+} rt_photon_map;
+rt_status rt_wavefront_set_photon_maps(rt_wavefront* wavefront, const rt_photon_map* maps, uint32_t count,
+                                       uint32_t samplesPerMap, uint32_t phase);
+
 /* Bucket bits (rt_photon_bucket_bitmap) of the photon grid the launch
  * parameters of later rt_render_sample calls point at, or null (the default)
  * to read every range.  The launch parameters keep the reference's layout

@@ -17,7 +17,9 @@ namespace {
 
 // positions: float3 at `stride` floats.
 __global__ __launch_bounds__(256) void photonKeysKernel(const float* positions, uint32_t stride, uint32_t n,
-                                                        float cellSize, uint32_t bucketCount, uint32_t* keys) {
+                                                        float cellSize, uint32_t bucketCount, uint32_t* keys,
+                                                        const uint32_t* nDevice) {
+    n = itemCount(n, nDevice);
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
         const float* p = positions + i * stride;
@@ -29,8 +31,21 @@ __global__ __launch_bounds__(256) void photonKeysKernel(const float* positions, 
 // position i starts every bucket in (key[i-1], key[i]], with key[-1] = -1 and
 // key[n] = bucketCount.  One streaming pass over the sorted keys; every entry
 // of offsets is written exactly once.
+//
+// Which of the two offset kernels runs is a matter of the photon count (dense maps: this one; maps with far
+// fewer photons than buckets: the search below).  With the count in device memory both are launched and
+// each looks at the count itself: `when` > 0 runs this kernel only for n >= bucketCount / 8, `when` < 0 only
+// for n below that, 0 always.
+__device__ inline bool offsetsTurn(int when, uint32_t n, uint32_t bucketCount) {
+    return when == 0 || (when > 0) == (n >= bucketCount / 8U);
+}
+
 __global__ __launch_bounds__(256) void photonOffsetsKernel(const uint32_t* sortedKeys, uint32_t n,
-                                                           uint32_t bucketCount, uint32_t* offsets) {
+                                                           uint32_t bucketCount, uint32_t* offsets,
+                                                           const uint32_t* nDevice, int when) {
+    n = itemCount(n, nDevice);
+    if (!offsetsTurn(when, n, bucketCount))
+        return;
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i > n)
         return;
@@ -44,7 +59,11 @@ __global__ __launch_bounds__(256) void photonOffsetsKernel(const uint32_t* sorte
 // fewer photons than buckets), where the boundary pass would leave long runs of
 // buckets to single threads.
 __global__ __launch_bounds__(256) void photonOffsetsSearchKernel(const uint32_t* sortedKeys, uint32_t n,
-                                                                 uint32_t bucketCount, uint32_t* offsets) {
+                                                                 uint32_t bucketCount, uint32_t* offsets,
+                                                                 const uint32_t* nDevice, int when) {
+    n = itemCount(n, nDevice);
+    if (!offsetsTurn(when, n, bucketCount))
+        return;
     const size_t b = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b > bucketCount)
         return;
@@ -63,10 +82,13 @@ __global__ __launch_bounds__(256) void photonOffsetsSearchKernel(const uint32_t*
 // each, scattered) into LDS and streams the 9216 contiguous bytes out as
 // 16-byte stores.
 __global__ __launch_bounds__(256) void photonReorderKernel(const rt_photon* photons, const uint32_t* order,
-                                                           uint32_t n, rt_photon* sorted) {
+                                                           uint32_t n, rt_photon* sorted, const uint32_t* nDevice) {
     __shared__ float4 stage[256 * 9 / 4];  // 9216 bytes
     float* flat = reinterpret_cast<float*>(stage);
     const size_t base = static_cast<size_t>(blockIdx.x) * 256;
+    n = itemCount(n, nDevice);
+    if (base >= n)
+        return;  // the whole workgroup
     const size_t i = base + threadIdx.x;
     if (i < n) {
         const float* src = reinterpret_cast<const float*>(photons + order[i]);
@@ -230,8 +252,11 @@ int log2Exact(uint32_t v) {
     return bits;
 }
 
+// The keys of a build live at the front of its scratch (GridScratch::keys[0]); a caller that already
+// knows a photon's bucket when it stores the photon writes them there itself (keysReady).
 rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount, uint32_t* counts,
-                    uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted, hipStream_t stream) {
+                    uint32_t* offsets, void* scan, size_t scanBytes, rt_photon* sorted, hipStream_t stream,
+                    const uint32_t* countDevice = nullptr, bool keysReady = false) {
     (void)counts;  // clobbered upstream; nothing here needs it
     if (bucketCount == 0 || (bucketCount & (bucketCount - 1U)) != 0)
         return failInvalid("bucketCount must be a power of two");
@@ -248,26 +273,30 @@ rt_status buildGrid(const rt_photon* photons, uint32_t count, float cellSize, ui
     Workspace* owned = nullptr;
     std::unique_lock<std::mutex> lock(workspaceMutex, std::defer_lock);
     if (!scan || scanBytes < needed) {
+        if (keysReady)
+            return failInvalid("keys were announced in a scratch buffer that is too small for the build");
         lock.lock();
         RT_TRY(ownedWorkspace(needed, stream, &owned));
         workspace = owned->data;
     }
     const GridScratch s = carve(workspace, count);
 
-    hipLaunchKernelGGL(photonKeysKernel, dim3(stridedGrid(count, 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const float*>(photons), 9U, count, cellSize, bucketCount, s.keys[0]);
+    if (!keysReady)
+        hipLaunchKernelGGL(photonKeysKernel, dim3(stridedGrid(count, 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const float*>(photons), 9U, count, cellSize, bucketCount, s.keys[0], countDevice);
     RT_HIP(hipGetLastError());
     int result = 0;
     const int bits = log2Exact(bucketCount) > 0 ? log2Exact(bucketCount) : 1;
-    RT_TRY(radixSortPairs<uint32_t>(s.keys, s.idx, count, bits, s.table, s.partials, stream, &result));
-    if (count >= bucketCount / 8U)
+    RT_TRY(radixSortPairs<uint32_t>(s.keys, s.idx, count, bits, s.table, s.partials, stream, &result, countDevice));
+    const bool dense = count >= bucketCount / 8U;
+    if (countDevice || dense)
         hipLaunchKernelGGL(photonOffsetsKernel, dim3(divUp(static_cast<size_t>(count) + 1U, 256)), dim3(256), 0, stream,
-                           s.keys[result], count, bucketCount, offsets);
-    else
+                           s.keys[result], count, bucketCount, offsets, countDevice, countDevice ? 1 : 0);
+    if (countDevice || !dense)
         hipLaunchKernelGGL(photonOffsetsSearchKernel, dim3(divUp(static_cast<size_t>(bucketCount) + 1U, 256)), dim3(256),
-                           0, stream, s.keys[result], count, bucketCount, offsets);
+                           0, stream, s.keys[result], count, bucketCount, offsets, countDevice, countDevice ? -1 : 0);
     hipLaunchKernelGGL(photonReorderKernel, dim3(divUp(count, 256)), dim3(256), 0, stream, photons, s.idx[result],
-                       count, sorted);
+                       count, sorted, countDevice);
     RT_HIP(hipGetLastError());
     if (owned) {
         RT_HIP(hipEventRecord(owned->busy, stream));
@@ -304,6 +333,21 @@ rt_status rt_build_photon_grid(const rt_photon* photons, uint32_t count, float c
     return RT_SUCCESS;
 }
 
+rt_status rt_build_photon_grid_counted(const rt_photon* photons, const uint32_t* countOnDevice, uint32_t maxCount,
+                                       float cellSize, uint32_t bucketCount, uint32_t* offsets, void* scan,
+                                       size_t scanBytes, rt_photon* sorted, int keysReady, void* stream) {
+    if (!countOnDevice)
+        return rt::failInvalid("countOnDevice is null");
+    return rt::buildGrid(photons, maxCount, cellSize, bucketCount, nullptr, offsets, scan, scanBytes, sorted,
+                         static_cast<hipStream_t>(stream), countOnDevice, keysReady != 0);
+}
+
+uint32_t* rt_photon_grid_keys(void* scan, size_t scanBytes, uint32_t maxCount, uint32_t bucketCount) {
+    if (!scan || maxCount == 0 || scanBytes < rt::scratchBytes(maxCount, bucketCount))
+        return nullptr;
+    return rt::carve(scan, maxCount).keys[0];
+}
+
 rt_status rt_build_photon_grid_static(const rt_photon* photons, uint32_t count, float cellSize, uint32_t bucketCount,
                                       uint32_t* offsets, rt_photon* sorted, void* stream) {
     if (count > RT_PHOTON_GRID_STATIC_MAX_PHOTONS) {
@@ -328,7 +372,8 @@ rt_status rt_photon_keys(const float* positions, uint32_t n, float cellSize, uin
     if (!positions || !keys)
         return rt::failInvalid("positions / keys is null");
     hipLaunchKernelGGL(rt::photonKeysKernel, dim3(rt::stridedGrid(n, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), positions, 3U, n, cellSize, bucketCount, keys);
+                       static_cast<hipStream_t>(stream), positions, 3U, n, cellSize, bucketCount, keys,
+                       static_cast<const uint32_t*>(nullptr));
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }

@@ -132,10 +132,19 @@ inline rt_status exclusiveScanU32(const uint32_t* in, uint32_t* out, size_t n, u
 
 // ---- radix sort -----------------------------------------------------------
 
+// The number of items a sort kernel works on: the host's `n`, or - when the count
+// only exists in device memory (a list whose length the GPU has just produced) -
+// the word at `nDevice`, cut at `n`.  The launch is then sized for `n`, and the
+// workgroups beyond the real count find nothing to do.
+__device__ inline uint32_t itemCount(uint32_t n, const uint32_t* nDevice) {
+    return nDevice ? min(*nDevice, n) : n;
+}
+
 template <typename K>
 __global__ __launch_bounds__(kSortBlock) void radixHistKernel(const K* keys, uint32_t n, int shift, uint32_t* table,
-                                                              uint32_t numBlocks) {
+                                                              uint32_t numBlocks, const uint32_t* nDevice) {
     __shared__ uint32_t hist[kRadix];
+    n = itemCount(n, nDevice);
     if (threadIdx.x < kRadix)
         hist[threadIdx.x] = 0;
     __syncthreads();
@@ -156,7 +165,8 @@ __global__ __launch_bounds__(kSortBlock) void radixHistKernel(const K* keys, uin
 template <typename K, bool FIRST>
 __global__ __launch_bounds__(kSortBlock) void radixScatterKernel(const K* keysIn, const uint32_t* idxIn, K* keysOut,
                                                                  uint32_t* idxOut, uint32_t n, int shift,
-                                                                 const uint32_t* table, uint32_t numBlocks) {
+                                                                 const uint32_t* table, uint32_t numBlocks,
+                                                                 const uint32_t* nDevice) {
     __shared__ uint32_t waveHist[kSortWaves][kRadix];
     __shared__ uint32_t digitBase[kRadix];
     __shared__ uint32_t waveSums[kSortWaves];
@@ -167,6 +177,9 @@ __global__ __launch_bounds__(kSortBlock) void radixScatterKernel(const K* keysIn
     const int wave = threadIdx.x >> 6;
     const unsigned long long lanesBelow = (1ULL << lane) - 1ULL;
     const size_t tileBase = static_cast<size_t>(blockIdx.x) * kSortTile;
+    n = itemCount(n, nDevice);
+    if (tileBase >= n)
+        return;  // the whole workgroup: a launch sized for more items than the device-side count
     const uint32_t tileCount = static_cast<uint32_t>(min(static_cast<size_t>(kSortTile), n - tileBase));
 
     for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortBlock)
@@ -259,10 +272,12 @@ __global__ __launch_bounds__(kSortBlock) void radixScatterKernel(const K* keysIn
 // initial payload of key i is i.  keys[0] holds the input; the sorted keys and
 // payloads end in keys[result] / idx[result] (result = number of passes & 1).
 // `table` holds sortTableEntries(n) uint32, `partials`
-// scanScratchEntries(sortTableEntries(n)).
+// scanScratchEntries(sortTableEntries(n)).  With `nDevice` the number of pairs is
+// min(*nDevice, n), read by the kernels when they run; the host never learns it.
 template <typename K>
 inline rt_status radixSortPairs(K* const keys[2], uint32_t* const idx[2], uint32_t n, int bits, uint32_t* table,
-                                uint32_t* partials, hipStream_t stream, int* result) {
+                                uint32_t* partials, hipStream_t stream, int* result,
+                                const uint32_t* nDevice = nullptr) {
     *result = 0;
     if (n == 0)
         return RT_SUCCESS;
@@ -272,14 +287,14 @@ inline rt_status radixSortPairs(K* const keys[2], uint32_t* const idx[2], uint32
         const int in = pass & 1, out = in ^ 1;
         const int shift = pass * 8;
         hipLaunchKernelGGL(radixHistKernel<K>, dim3(blocks), dim3(kSortBlock), 0, stream, keys[in], n, shift, table,
-                           blocks);
+                           blocks, nDevice);
         RT_TRY(exclusiveScanU32(table, table, sortTableEntries(n), partials, stream));
         if (pass == 0)
             hipLaunchKernelGGL((radixScatterKernel<K, true>), dim3(blocks), dim3(kSortBlock), 0, stream, keys[in],
-                               idx[in], keys[out], idx[out], n, shift, table, blocks);
+                               idx[in], keys[out], idx[out], n, shift, table, blocks, nDevice);
         else
             hipLaunchKernelGGL((radixScatterKernel<K, false>), dim3(blocks), dim3(kSortBlock), 0, stream, keys[in],
-                               idx[in], keys[out], idx[out], n, shift, table, blocks);
+                               idx[in], keys[out], idx[out], n, shift, table, blocks, nDevice);
         RT_HIP(hipGetLastError());
     }
     *result = passes & 1;

@@ -73,6 +73,29 @@ struct Buffers {
     uint32_t* photonFlags;
 };
 
+// The photon maps a pass gathers from.  The reference rebuilds its one map every fourth sample
+// (renderer.cpp:177, 780-781); a pass over more samples than that needs the map of each group of samples it
+// holds, so the gather kernels pick a query's map by the sample its path belongs to: sample k of the pass
+// (path / perSample) reads map (phase + k) / samplesPerMap.  count == 0: the one map of the launch parameters.
+struct PhotonMaps {
+    rt_photon_map maps[RT_MAX_PHOTON_MAPS];
+    uint32_t count, samplesPerMap, phase, perSample;
+
+    __device__ void pick(const rt_launch_params& p, const uint32_t* bits, uint32_t path, const rt_photon*& sorted,
+                         const uint32_t*& cellStart, const uint32_t*& bucketBits) const {
+        if (count == 0U) {
+            sorted = p.sortedPhotons;
+            cellStart = p.photonCellStart;
+            bucketBits = bits;
+            return;
+        }
+        const uint32_t map = min((phase + path / perSample) / samplesPerMap, count - 1U);
+        sorted = maps[map].sortedPhotons;
+        cellStart = maps[map].cellStart;
+        bucketBits = maps[map].bucketBits;
+    }
+};
+
 // Slots for the lanes with `want` set: a wave ballot, a workgroup prefix and one
 // atomic on *counter per workgroup.  Every thread of the workgroup calls this.
 __device__ inline uint32_t allocateSlots(bool want, uint32_t* counter, uint32_t* shared /* kSlotWords */) {
@@ -586,7 +609,8 @@ constexpr unsigned kHeavyGatherBlocks = 512;
 // estimate to the caustic sum of its path.  A path has at most one query per bounce, so the
 // order of the queue does not enter any sum.  Queries over the photon budget go on to
 // causticGatherHeavyKernel.
-__global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKernel(rt_launch_params p, Buffers b) {
+__global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKernel(rt_launch_params p, Buffers b,
+                                                                                    PhotonMaps maps) {
     const uint32_t n = b.counts[3];
     if (blockIdx.x * kShadeBlock >= n)
         return;
@@ -597,10 +621,13 @@ __global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKer
         const float4 point = b.gather[0][query];
         const float4 normal = b.gather[1][query];
         float fx, fy, fz;
-        finished = gatherFlux(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y,
-                              point.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered, b.bucketBits, b.heavyBudget);
+        const uint32_t path = __float_as_uint(point.w);
+        const rt_photon* sorted;
+        const uint32_t *cellStart, *bucketBits;
+        maps.pick(p, b.bucketBits, path, sorted, cellStart, bucketBits);
+        finished = gatherFlux(sorted, cellStart, p.photonBucketCount, p.photonRadius, point.x, point.y,
+                              point.z, normal.x, normal.y, normal.z, fx, fy, fz, &gathered, bucketBits, b.heavyBudget);
         if (finished) {
-            const uint32_t path = __float_as_uint(point.w);
             const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
             const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
             b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
@@ -629,7 +656,7 @@ __global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKer
 
 // The queries causticGatherKernel passed on, one per wave (gatherFluxWave); the waves of the
 // launch take them in turn.
-__global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launch_params p, Buffers b) {
+__global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launch_params p, Buffers b, PhotonMaps maps) {
     const uint32_t n = b.counts[4];
     const uint32_t waves = gridDim.x * (kShadeBlock / 64);
     const uint32_t lane = threadIdx.x & 63U;
@@ -639,10 +666,13 @@ __global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launc
         const float4 normal = b.gather[1][query];
         float fx, fy, fz;
         uint32_t gathered = 0;
-        gatherFluxWave(p.sortedPhotons, p.photonCellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
-                       normal.x, normal.y, normal.z, fx, fy, fz, gathered, b.bucketBits);
+        const uint32_t path = __float_as_uint(point.w);
+        const rt_photon* sorted;
+        const uint32_t *cellStart, *bucketBits;
+        maps.pick(p, b.bucketBits, path, sorted, cellStart, bucketBits);
+        gatherFluxWave(sorted, cellStart, p.photonBucketCount, p.photonRadius, point.x, point.y, point.z,
+                       normal.x, normal.y, normal.z, fx, fy, fz, gathered, bucketBits);
         if (lane == 0U) {
-            const uint32_t path = __float_as_uint(point.w);
             const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
             const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
             b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
@@ -886,15 +916,22 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
 
 // Appends the batch's stored photons behind *photonCount in emission order
 // (offsets = exclusive scan of the flags; offsets[count] = photons of the batch).
+// With `keys` the photon's bucket key goes to keys[slot] (photon_hash.cuh:10-24 at cell size p.photonRadius):
+// the position is in registers here, where the grid build would read the whole record again for it.
 __global__ __launch_bounds__(256) void photonCompactKernel(rt_launch_params p, uint32_t count, const uint32_t* offsets,
-                                                           Buffers b) {
+                                                           Buffers b, uint32_t* keys) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
         return;
     if (offsets[i + 1] != offsets[i]) {
         const uint32_t slot = *p.photonCount + offsets[i];
-        if (slot < p.photonCapacity)
-            p.photons[slot] = b.photonTemp[i];
+        if (slot < p.photonCapacity) {
+            const rt_photon photon = b.photonTemp[i];
+            p.photons[slot] = photon;
+            if (keys)
+                keys[slot] = bucketOfPosition(photon.position.x, photon.position.y, photon.position.z, p.photonRadius,
+                                              p.photonBucketCount);
+        }
     }
 }
 
@@ -923,10 +960,55 @@ struct rt_wavefront {
     rt::Buffers buffers{};
     std::vector<void*> allocations;
     uint32_t* scanCounts = nullptr;    // capacity + 1
+    uint32_t* photonKeys = nullptr;    // bucket keys of stored photons go here too (rt_wavefront_set_photon_keys)
+    rt::PhotonMaps photonMaps{};       // the maps of the next pass (rt_wavefront_set_photon_maps); count 0: the parameters' map
+    uint32_t uses = RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS;
     uint32_t* scanPartials = nullptr;
 };
 
 using namespace rt;
+
+namespace {
+
+// Every device array of a wavefront state in one place: `visit(pointer, count, uses)` is called once per
+// array with the kinds of pass that need it, so the allocation and the size query cannot drift apart.
+template <typename Visit>
+void forEachArray(rt_wavefront& w, size_t maxPaths, Visit&& visit) {
+    constexpr uint32_t camera = RT_WAVEFRONT_FOR_CAMERA, photons = RT_WAVEFRONT_FOR_PHOTONS, both = camera | photons;
+    Buffers& b = w.buffers;
+    for (int k = 0; k < 2; ++k) {
+        visit(b.rayOrigin[k], maxPaths, both);
+        visit(b.rayDirection[k], maxPaths, both);
+        visit(b.rayPath[k], maxPaths, both);
+    }
+    visit(b.hits, maxPaths, both);
+    visit(b.hitInstance, maxPaths, both);
+    visit(b.shadowOrigin, maxPaths, camera);
+    visit(b.shadowDirection, maxPaths, camera);
+    visit(b.shadowContribution, maxPaths, camera);
+    visit(b.shadowPath, maxPaths, camera);
+    visit(b.shadowTarget, maxPaths, camera);
+    for (int k = 0; k < 2; ++k) {
+        visit(b.rng[k], maxPaths, both);
+        visit(b.throughput[k], maxPaths, both);
+        visit(b.lastOrigin[k], maxPaths, both);
+    }
+    for (int k = 0; k < 6; ++k)
+        if (k != 1 && k != 2)
+            visit(b.sample[k], maxPaths, camera);
+    for (int k = 0; k < 4; ++k)
+        visit(b.gather[k], maxPaths, camera);
+    visit(b.heavyQueries, maxPaths, camera);
+    visit(b.counts, size_t{8}, both);
+    visit(b.feed, static_cast<size_t>(kFeedWords), both);
+    visit(b.stats, size_t{8}, both);
+    visit(b.photonTemp, maxPaths, photons);
+    visit(b.photonFlags, maxPaths + 1, photons);
+    visit(w.scanCounts, maxPaths + 1, photons);
+    visit(w.scanPartials, scanScratchEntries(maxPaths + 1), photons);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -944,61 +1026,51 @@ void rt_wavefront_destroy(rt_wavefront* w) {
     delete w;
 }
 
-rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
+rt_status rt_wavefront_state_bytes(uint32_t maxPaths, uint32_t uses, size_t* bytes) {
+    if (!bytes)
+        return failInvalid("bytes is null");
+    if (uses == 0 || (uses & ~(RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS)))
+        return failInvalid("uses: RT_WAVEFRONT_FOR_CAMERA and / or RT_WAVEFRONT_FOR_PHOTONS");
+    rt_wavefront scratch;
+    size_t total = 0;
+    forEachArray(scratch, maxPaths, [&](auto*& pointer, size_t count, uint32_t neededBy) {
+        using T = std::remove_reference_t<decltype(*pointer)>;
+        if (neededBy & uses)
+            total += alignUp(sizeof(T) * count, 256);
+    });
+    *bytes = total;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_create_for(uint32_t maxPaths, uint32_t uses, rt_wavefront** out) {
     if (!out)
         return failInvalid("out is null");
     *out = nullptr;
     if (maxPaths == 0)
         return failInvalid("maxPaths is zero");
+    if (uses == 0 || (uses & ~(RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS)))
+        return failInvalid("uses: RT_WAVEFRONT_FOR_CAMERA and / or RT_WAVEFRONT_FOR_PHOTONS");
     auto* w = new rt_wavefront();
+    w->uses = uses;
     RT_HIP(hipGetDevice(&w->device));
     rt_status status = RT_SUCCESS;
-    auto allocate = [&](auto*& pointer, size_t count) {
+    forEachArray(*w, maxPaths, [&](auto*& pointer, size_t count, uint32_t neededBy) {
         using T = std::remove_reference_t<decltype(*pointer)>;
         void* raw = nullptr;
-        if (status != RT_SUCCESS)
+        if (status != RT_SUCCESS || !(neededBy & uses))
             return;
         const hipError_t e = hipMalloc(&raw, sizeof(T) * count);
         if (e != hipSuccess) {
+            (void)hipGetLastError();  // the failure is reported through the status; the next call starts clean
             status = fail(e, "hipMalloc (wavefront buffers)");
             return;
         }
         w->allocations.push_back(raw);
         pointer = static_cast<T*>(raw);
-    };
+    });
     Buffers& b = w->buffers;
     b.capacity = maxPaths;
-    for (int k = 0; k < 2; ++k) {
-        allocate(b.rayOrigin[k], maxPaths);
-        allocate(b.rayDirection[k], maxPaths);
-        allocate(b.rayPath[k], maxPaths);
-    }
-    allocate(b.hits, maxPaths);
-    allocate(b.hitInstance, maxPaths);
-    allocate(b.shadowOrigin, maxPaths);
-    allocate(b.shadowDirection, maxPaths);
-    allocate(b.shadowContribution, maxPaths);
-    allocate(b.shadowPath, maxPaths);
-    allocate(b.shadowTarget, maxPaths);
-    for (int k = 0; k < 2; ++k) {
-        allocate(b.rng[k], maxPaths);
-        allocate(b.throughput[k], maxPaths);
-        allocate(b.lastOrigin[k], maxPaths);
-    }
-    for (int k = 0; k < 6; ++k)
-        if (k != 1 && k != 2)
-            allocate(b.sample[k], maxPaths);
-    for (int k = 0; k < 4; ++k)
-        allocate(b.gather[k], maxPaths);
-    allocate(b.heavyQueries, maxPaths);
     b.heavyBudget = kHeavyPhotons;
-    allocate(b.counts, 8);
-    allocate(b.feed, kFeedWords);
-    allocate(b.stats, 8);
-    allocate(b.photonTemp, maxPaths);
-    allocate(b.photonFlags, static_cast<size_t>(maxPaths) + 1);
-    allocate(w->scanCounts, static_cast<size_t>(maxPaths) + 1);
-    allocate(w->scanPartials, scanScratchEntries(static_cast<size_t>(maxPaths) + 1));
     if (status == RT_SUCCESS) {
         if (hipMemset(b.counts, 0, sizeof(uint32_t) * 8) != hipSuccess ||
             hipMemset(b.stats, 0, sizeof(unsigned long long) * 8) != hipSuccess)
@@ -1010,6 +1082,10 @@ rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
     }
     *out = w;
     return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out) {
+    return rt_wavefront_create_for(maxPaths, RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS, out);
 }
 
 rt_status rt_wavefront_stats(rt_wavefront* w, uint64_t* out8, int reset, void* stream) {
@@ -1056,6 +1132,33 @@ rt_status rt_wavefront_set_accumulate_events(rt_wavefront* w, void* waitFor, voi
         return failInvalid("null pointer");
     w->accumulateAfter = static_cast<hipEvent_t>(waitFor);
     w->accumulateSignal = static_cast<hipEvent_t>(record);
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_photon_keys(rt_wavefront* w, uint32_t* keys) {
+    if (!w)
+        return failInvalid("null pointer");
+    w->photonKeys = keys;
+    return RT_SUCCESS;
+}
+
+rt_status rt_wavefront_set_photon_maps(rt_wavefront* w, const rt_photon_map* maps, uint32_t count, uint32_t samplesPerMap,
+                                       uint32_t phase) {
+    if (!w)
+        return failInvalid("null pointer");
+    if (count > RT_MAX_PHOTON_MAPS)
+        return failInvalid("more photon maps than RT_MAX_PHOTON_MAPS");
+    if (count && (!maps || samplesPerMap == 0 || phase >= samplesPerMap))
+        return failInvalid("photon maps: null table, no samples per map, or a phase beyond them");
+    for (uint32_t k = 0; k < count; ++k)
+        if (!maps[k].sortedPhotons || !maps[k].cellStart)
+            return failInvalid("photon maps: a map without sorted photons or cell starts");
+    w->photonMaps = PhotonMaps{};
+    for (uint32_t k = 0; k < count; ++k)
+        w->photonMaps.maps[k] = maps[k];
+    w->photonMaps.count = count;
+    w->photonMaps.samplesPerMap = count ? samplesPerMap : 1U;
+    w->photonMaps.phase = phase;
     return RT_SUCCESS;
 }
 
@@ -1204,6 +1307,10 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
     map.count = map.perSample * map.samples;
     const uint32_t count = map.count;
     const Buffers& b = w->buffers;
+    if (!(w->uses & RT_WAVEFRONT_FOR_CAMERA))
+        return failInvalid("this wavefront state was created for photon passes only");
+    PhotonMaps photonMaps = w->photonMaps;
+    photonMaps.perSample = map.perSample;
     const unsigned blocks = divUp(count, kShadeBlock);
     const unsigned resident = std::max<unsigned>(
         1U, static_cast<unsigned>(static_cast<uint64_t>(persistentBlocks(w->device)) * w->shareNumerator / w->shareDenominator));
@@ -1237,10 +1344,10 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
             hipLaunchKernelGGL(shadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
                                scene->hitGroups, b, which, depth);
             if (params->photonRadius > 0.0f) {
-                hipLaunchKernelGGL(causticGatherKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, b);
+                hipLaunchKernelGGL(causticGatherKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, b, photonMaps);
                 if (b.heavyBudget != 0xffffffffU)
                     hipLaunchKernelGGL(causticGatherHeavyKernel, dim3(std::min(blocks, kHeavyGatherBlocks)),
-                                       dim3(kShadeBlock), 0, s, *params, b);
+                                       dim3(kShadeBlock), 0, s, *params, b, photonMaps);
             }
         }
         // the shadow rays of this bounce travel with the extend rays of the next
@@ -1334,8 +1441,14 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
     RT_TRY(checkLaunch(w, params, scene));
     if (!params->photons || !params->photonCount)
         return failInvalid("launch parameters carry no photon buffers");
+    if (!(w->uses & RT_WAVEFRONT_FOR_PHOTONS))
+        return failInvalid("this wavefront state was created for camera passes only");
     auto s = static_cast<hipStream_t>(stream);
     const Buffers& b = w->buffers;
+    uint32_t* keys = w->photonKeys;
+    if (keys && (!(params->photonRadius > 0.0f) || params->photonBucketCount == 0 ||
+                 (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
+        return failInvalid("photon keys asked for without a cell size (photonRadius) and a power-of-two bucket count");
     uint32_t done = 0;
     while (done < emissionCount) {
         const uint32_t count = std::min(b.capacity, emissionCount - done);
@@ -1359,7 +1472,7 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
         RT_HIP(hipMemsetAsync(b.photonFlags + count, 0, sizeof(uint32_t), s));
         RT_TRY(exclusiveScanU32(b.photonFlags, w->scanCounts, static_cast<size_t>(count) + 1, w->scanPartials, s));
         hipLaunchKernelGGL(photonCompactKernel, dim3(divUp(count, 256)), dim3(256), 0, s, *params, count,
-                           w->scanCounts, b);
+                           w->scanCounts, b, keys);
         hipLaunchKernelGGL(photonCountKernel, dim3(1), dim3(64), 0, s, *params, count, w->scanCounts);
         RT_HIP(hipGetLastError());
         done += count;

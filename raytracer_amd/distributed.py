@@ -162,6 +162,9 @@ class DistributedRenderer:
         self.renderer.set_manual_photon_passes(True)
         self.renderer.set_row_interleave(self.rank, self.world)
         self.exchanges = []  # per photon pass: dict(ms, photons, kept, bytes_sent, bytes_received)
+        # The exchange runs on a stream of its own: the default stream would wait for the samples that are
+        # still rendering on the renderer's streams, and the exchange has nothing to do with them.
+        self.stream = torch.cuda.Stream()
 
     def _photon_pass(self):
         torch, r, R = self.torch, self.renderer, self.R
@@ -174,16 +177,17 @@ class DistributedRenderer:
         t0 = time.perf_counter()
         staging = R.device_view(r.photon_staging_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
         dest = R.device_view(r.photon_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
-        if self.on_device:
-            counts = gather_counts(stored, self.group, "cuda")
-            kept, sent, received = exchange_photons_into(dest, staging, counts, self.group)
-            torch.cuda.current_stream().synchronize()  # the pass is timed; the grid build would order itself
-        else:
-            counts = gather_counts(stored, self.group, "cpu")
-            host = torch.empty((min(sum(counts), capacity), PHOTON_FLOATS), dtype=torch.float32)
-            kept, sent, received = exchange_photons_into(host, staging[:stored].cpu(), counts, self.group)
-            dest[:kept].copy_(host[:kept])
-            torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            if self.on_device:
+                counts = gather_counts(stored, self.group, "cuda")
+                kept, sent, received = exchange_photons_into(dest, staging, counts, self.group)
+            else:
+                counts = gather_counts(stored, self.group, "cpu")
+                host = torch.empty((min(sum(counts), capacity), PHOTON_FLOATS), dtype=torch.float32)
+                kept, sent, received = exchange_photons_into(host, staging[:stored].cpu(), counts, self.group)
+                dest[:kept].copy_(host[:kept])
+        # the grid build that follows runs on the renderer's photon stream: the merged list must be complete
+        self.stream.synchronize()
         self.exchanges.append(dict(ms=(time.perf_counter() - t0) * 1e3, photons=sum(counts), kept=kept,
                                    bytes_sent=sent, bytes_received=received))
         r.finish_photon_pass(kept)

@@ -48,6 +48,9 @@ SYMBOLS = {
     "rt_build_photon_grid": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "rt_build_photon_grid_async": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rt_build_photon_grid_static": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp, _vp]),
+    "rt_build_photon_grid_counted": (C.c_int, [_vp, _vp, _u32, _f32, _u32, _vp, _vp, _sz, _vp, C.c_int, _vp]),
+    "rt_photon_grid_keys": (_vp, [_vp, _sz, _u32, _u32]),
+    "rt_wavefront_set_photon_keys": (C.c_int, [_vp, _vp]),
     "rt_photon_keys": (C.c_int, [_vp, _u32, _f32, _u32, _vp, _vp]),
     "rt_photon_gather": (C.c_int, [_vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, _vp]),
     "rt_blas_build": (C.c_int, [_vp, _u32, _u32, _vp, _u32, _vp, C.POINTER(_vp)]),
@@ -67,6 +70,9 @@ SYMBOLS = {
     "rt_scene_set_geometry": (C.c_int, [_vp, _vp, _u32]),
     "rt_wavefront_create": (C.c_int, [_u32, C.POINTER(_vp)]),
     "rt_wavefront_destroy": (None, [_vp]),
+    "rt_wavefront_create_for": (C.c_int, [_u32, _u32, C.POINTER(_vp)]),
+    "rt_wavefront_state_bytes": (C.c_int, [_u32, _u32, C.POINTER(C.c_size_t)]),
+    "rt_wavefront_set_photon_maps": (C.c_int, [_vp, _vp, _u32, _u32, _u32]),
     "rt_render_sample": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
     "rt_render_sample_seeded": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "rt_render_sample_bands": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
@@ -188,6 +194,29 @@ class PhotonGrid:
             check(lib.rt_build_photon_grid_async(*args, _stream(stream)))
         self.count = n
         self.cell_size = float(cell_size)
+
+    def build_counted(self, photons, count, cell_size, keys_ready=False, stream=None):
+        """rt_build_photon_grid_counted: photons is the whole (capacity, 9) list, `count` a (1,) int32 device
+        tensor with its length, which the host never reads.  keys_ready: the caller has put the bucket keys
+        at keys_view() already."""
+        import torch
+        assert photons.is_cuda and photons.dtype == torch.float32 and photons.is_contiguous()
+        assert count.is_cuda and count.dtype == torch.int32 and count.numel() == 1
+        most = photons.shape[0]
+        assert most <= self.capacity
+        check(load().rt_build_photon_grid_counted(_ptr(photons), _ptr(count), most, float(cell_size), self.bucket_count,
+                                                  _ptr(self.offsets), _ptr(self.scratch), self.scratch_bytes,
+                                                  _ptr(self.sorted), int(keys_ready), _stream(stream)))
+        self.count = None  # only the device knows
+        self.cell_size = float(cell_size)
+
+    def keys_view(self, most):
+        """The `most` bucket keys a counted build over this grid's scratch starts from, as an int32 tensor."""
+        import torch
+        address = load().rt_photon_grid_keys(_ptr(self.scratch), self.scratch_bytes, most, self.bucket_count)
+        assert address, "the grid's scratch is too small for that many photons"
+        offset = address - self.scratch.data_ptr()
+        return self.scratch[offset:offset + 4 * most].view(torch.int32)
 
     def build_static(self, photons, cell_size, stream=None):
         """rt_build_photon_grid_static: the build through the library's static scratch (allocates nothing)."""

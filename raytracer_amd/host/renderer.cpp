@@ -398,18 +398,43 @@ struct Renderer::Impl {
     std::size_t aovBytes = 0, outputOffset = 0, outputBytes = 0;
 
     // ---- photon map -----------------------------------------------------------------------------------
+    // The reference keeps one map and rebuilds it before every fourth sample (renderer.cpp:177, 780-781).  Here the
+    // maps of consecutive groups of four samples live side by side in a ring, so that a pass can hold the samples
+    // of several groups (each gathering from its own group's map) and the next pass's maps can be traced while
+    // this pass still renders.  A map is the sorted photon list, its bucket table and its bucket bits; the
+    // unsorted list, the counter and the sort's scratch serve one photon pass at a time, on the photon stream.
     DevicePool photonPool;
     struct PhotonBlocks {
-        std::size_t photons = 0, sorted = 0, cellCounts = 0, cellStart = 0, counter = 0, scan = 0, bucketBits = 0;
+        std::size_t photons = 0, cellCounts = 0, counter = 0, scan = 0;
         std::size_t scanBytes = 0;
     } photonAt;
+    static constexpr std::uint32_t kNoEpoch = 0xffffffffU;
+    struct PhotonMap {
+        std::size_t sorted = 0, cellStart = 0, bucketBits = 0;  // offsets in the photon pool
+        std::uint32_t epoch = kNoEpoch;                         // the group of four samples whose photons it holds
+        hipEvent_t built = nullptr;                             // recorded on the photon stream behind its build
+        std::vector<hipEvent_t> read;                           // per part: behind the part's last pass that gathers from it
+        std::vector<char> readRecorded;
+    };
+    std::vector<PhotonMap> maps;
+    std::uint32_t currentMap = 0;       // the map of the pass that is being built step by step (manual passes)
+    hipStream_t photonStream = nullptr;
+    std::uint32_t* storedOnHost = nullptr;  // pinned word the stored count of a manual pass is copied to
     rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
     std::uint32_t photonWavefrontCapacity = 0;
     float gatherRadius = 0.0f;
     bool caustics = false;
     bool overflowReported = false;
+    // The stored count of a pass stays on the device; a copy of it travels to pinned host memory behind the
+    // pass and is looked at when it has arrived (reportOverflow), for the reference's warning.
+    struct StoredCount {
+        std::uint32_t* value = nullptr;  // pinned host memory
+        hipEvent_t arrived = nullptr;
+        bool pending = false;
+    };
+    std::vector<StoredCount> storedCounts;
+    std::uint32_t* photonKeys = nullptr;  // inside the sort's scratch: the bucket keys the tracer writes
     bool manualPhotonPasses = false;
-    bool photonPassPending = true;
 
     // ---- launch state ---------------------------------------------------------------------------------
     rt_launch_params launch;
@@ -442,9 +467,11 @@ struct Renderer::Impl {
     // when that grows or shrinks to less than half: a GPU that takes one share of many has state for its share.
     std::uint64_t partCapacity = 0;                     // pixels one part has room for
     std::uint32_t shareNumerator = 0, shareDenominator = 0;  // setRayShare; 0: the policy of createParts
-    // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x 332 bytes
+    // wavefront state a renderer takes by itself: pixels x samples per pass x passes in flight x the bytes the
+    // engine states per path, at most this much and at most half of the memory that is free when the state is made
     static constexpr std::uint64_t kStateBudget = 24ULL << 30;
-    static constexpr std::uint64_t kStateBytesPerPath = 332;
+    // a pass with a photon map holds at most this many groups of four samples
+    static constexpr std::uint32_t kMapsPerPass = 8;
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
     // launches leave the GPU half idle in their tails; four of them side by side fill it)
@@ -452,9 +479,23 @@ struct Renderer::Impl {
 
     ~Impl() {
         (void)hipDeviceSynchronize();
+        for (StoredCount& count : storedCounts)
+            if (count.pending)
+                warnIfOverfull(*count.value);  // everything has arrived behind the synchronisation
         destroyParts();
+        destroyMaps();
+        if (photonStream)
+            (void)hipStreamDestroy(photonStream);
+        if (storedOnHost)
+            (void)hipHostFree(storedOnHost);
         if (photonWavefront)
             rt_wavefront_destroy(photonWavefront);
+        for (StoredCount& count : storedCounts) {
+            if (count.value)
+                (void)hipHostFree(count.value);
+            if (count.arrived)
+                (void)hipEventDestroy(count.arrived);
+        }
         if (tree)
             rt_scene_destroy(tree);
         for (Mesh& mesh : meshes)
@@ -637,43 +678,84 @@ struct Renderer::Impl {
             *targets[k] = framePool.at<rt_float4>(aovOffset[static_cast<std::size_t>(k)]);
     }
 
-    // Photon list, sorted copy, the two bucket tables, the counter, the sort's scratch and the bucket
-    // bits (renderer.cpp:537-550) in one allocation.
+    // Photon list, the counter, the sort's scratch and, per map of the ring, the sorted copy, the bucket table
+    // and the bucket bits (renderer.cpp:537-550) in one allocation.
     void setPhotonSizes(std::uint32_t emissions, std::uint32_t capacity, std::uint32_t buckets) {
         launch.photonEmissions = emissions;
         launch.photonCapacity = capacity;
         launch.photonBucketCount = buckets;
+        allocateMaps(std::max<std::size_t>(1, maps.size()));
+    }
+
+    void destroyMaps() {
+        for (PhotonMap& map : maps) {
+            if (map.built)
+                (void)hipEventDestroy(map.built);
+            for (hipEvent_t event : map.read)
+                if (event)
+                    (void)hipEventDestroy(event);
+        }
+        maps.clear();
+    }
+
+    void allocateMaps(std::size_t count) {
+        hipOk(hipDeviceSynchronize());
+        destroyMaps();
+        if (!photonStream)
+            hipOk(hipStreamCreate(&photonStream));
+        if (!storedOnHost)
+            hipOk(hipHostMalloc(reinterpret_cast<void**>(&storedOnHost), sizeof(std::uint32_t), hipHostMallocDefault));
+        const std::uint32_t capacity = launch.photonCapacity, buckets = launch.photonBucketCount;
         Layout layout;
         const std::size_t listBytes = static_cast<std::size_t>(capacity) * sizeof(rt_photon);
         const std::size_t tableBytes = (static_cast<std::size_t>(buckets) + 1U) * sizeof(std::uint32_t);
         const std::size_t bitBytes = std::max<std::size_t>(1, buckets / 32U) * sizeof(std::uint32_t);
         photonAt.photons = layout.take(listBytes);
-        photonAt.sorted = layout.take(listBytes);
         photonAt.cellCounts = layout.take(tableBytes);
-        photonAt.cellStart = layout.take(tableBytes);
         photonAt.counter = layout.take(sizeof(std::uint32_t));
-        photonAt.scanBytes = photonScanStorage(buckets);
+        // room for the sort of a full photon list (the reference sizes its scan for the buckets alone)
+        photonAt.scanBytes = std::max(photonScanStorage(buckets), rt_photon_grid_scratch_bytes(capacity, buckets));
         photonAt.scan = layout.take(photonAt.scanBytes);
-        photonAt.bucketBits = layout.take(bitBytes);
+        maps.resize(count);
+        for (PhotonMap& map : maps) {
+            map.sorted = layout.take(listBytes);
+            map.cellStart = layout.take(tableBytes);
+            map.bucketBits = layout.take(bitBytes);
+        }
         photonPool.allocate(layout.bytes());
-        // until the first pass every bucket is empty
-        hipOk(hipMemset(photonPool.at<void>(photonAt.cellStart), 0, tableBytes));
-        hipOk(hipMemset(photonPool.at<void>(photonAt.bucketBits), 0, bitBytes));
+        for (PhotonMap& map : maps) {
+            // until its first pass every bucket of a map is empty
+            hipOk(hipMemset(photonPool.at<void>(map.cellStart), 0, tableBytes));
+            hipOk(hipMemset(photonPool.at<void>(map.bucketBits), 0, bitBytes));
+            hipOk(hipEventCreateWithFlags(&map.built, hipEventDisableTiming));
+            map.read.assign(parts.size(), nullptr);
+            map.readRecorded.assign(parts.size(), 0);
+            for (hipEvent_t& event : map.read)
+                hipOk(hipEventCreateWithFlags(&event, hipEventDisableTiming));
+        }
+        currentMap = 0;
         launch.photons = photonPool.at<rt_photon>(photonAt.photons);
         launch.photonCount = photonPool.at<std::uint32_t>(photonAt.counter);
-        launch.sortedPhotons = photonPool.at<const rt_photon>(photonAt.sorted);
-        launch.photonCellStart = photonPool.at<const std::uint32_t>(photonAt.cellStart);
-        shareBucketBits();
+        launch.sortedPhotons = photonPool.at<const rt_photon>(maps[0].sorted);
+        launch.photonCellStart = photonPool.at<const std::uint32_t>(maps[0].cellStart);
+        photonKeys = rt_photon_grid_keys(photonPool.at<void>(photonAt.scan), photonAt.scanBytes, capacity, buckets);
     }
 
-    void shareBucketBits() {
+    // Maps the ring must hold: those of the passes in flight.  A pass of n samples that starts anywhere in a
+    // group of four touches (n + 6) / 4 groups at most, n / 4 when passes start on a group's first sample.
+    std::size_t mapsWanted() const {
+        if (!caustics)
+            return 1;
+        const std::uint32_t perPass = batch % kPhotonRebuildInterval == 0U ? batch / kPhotonRebuildInterval
+                                                                          : (batch + 6U) / kPhotonRebuildInterval;
+        return static_cast<std::size_t>(std::max(perPass, 1U)) * depth;
+    }
+
+    void shareLightIndex() {
         for (Part& part : parts)
-            if (part.wavefront) {
-                engineOk(rt_wavefront_set_bucket_bitmap(part.wavefront, photonPool.at<const std::uint32_t>(photonAt.bucketBits)),
-                         "rt_wavefront_set_bucket_bitmap");
+            if (part.wavefront)
                 engineOk(rt_wavefront_set_light_index(part.wavefront, lightIndex, launch.lightCount),
                          "rt_wavefront_set_light_index");
-            }
     }
 
     void applyProfile(Profile profile) {  // renderer.cpp:226, 251, 735-737
@@ -696,8 +778,13 @@ struct Renderer::Impl {
 
     void restart() {  // renderer.cpp:716-728
         hipOk(hipDeviceSynchronize());  // samples may still be in flight on the parts' streams
+        reportOverflow(true);
         for (Part& part : parts)
             part.recorded = false;
+        for (PhotonMap& map : maps) {
+            map.epoch = kNoEpoch;
+            std::fill(map.readRecorded.begin(), map.readRecorded.end(), 0);
+        }
         for (std::size_t offset : aovOffset)
             hipOk(hipMemset(framePool.at<void>(offset), 0, aovBytes));
         launch.photonPass = 0;
@@ -707,76 +794,170 @@ struct Renderer::Impl {
     }
 
     // ---- photon pass (renderer.cpp:741-777), in the three steps a multi-GPU driver interleaves with
-    // its exchange
-    void beginPhotonPass() {  // :742-745
-        flush();  // the samples that are waiting read the map this pass replaces
-        launch.photonRadius = gatherRadius;
-        hipOk(hipMemset(photonPool.at<void>(photonAt.counter), 0, sizeof(std::uint32_t)));
+    // its exchange.  Everything of a pass runs on the photon stream.
+
+    // The group of four samples the next render() call belongs to, and whether its map is missing.
+    std::uint32_t nextEpoch() const { return (sample + pending) / kPhotonRebuildInterval; }
+    bool photonPassDue() const {  // renderer.cpp:780
+        if (!(launch.photonRadius > 0.0f) || (sample + pending) % kPhotonRebuildInterval != 0U)
+            return false;
+        return maps.empty() || parts.empty() || maps[nextEpoch() % maps.size()].epoch != nextEpoch();
     }
 
-    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {  // :746-769
-        // The photon pass has wavefront state of its own, sized for a whole pass (at most 2^24 paths,
-        // 332 bytes each): every batch ends with the drain of its ray launches, so few large batches
-        // beat many frame-sized ones.
-        const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
-        if (!photonWavefront || photonWavefrontCapacity < wanted) {
-            hipOk(hipDeviceSynchronize());
-            if (photonWavefront)
-                rt_wavefront_destroy(photonWavefront);
-            photonWavefront = nullptr;
-            engineOk(rt_wavefront_create(wanted, &photonWavefront), "rt_wavefront_create");
-            engineOk(rt_wavefront_set_light_index(photonWavefront, lightIndex, launch.lightCount), "rt_wavefront_set_light_index");
-            photonWavefrontCapacity = wanted;
+    // The ring slot for the map of `epoch`, free to be overwritten: calls that wait for their pass and still read
+    // the map the slot holds go out first, and the photon stream waits for the passes that gather from it.
+    PhotonMap& claimMap(std::uint32_t epoch) {
+        ensureParts();
+        PhotonMap* map = &maps[epoch % maps.size()];
+        if (pending > 0 && map->epoch != kNoEpoch && map->epoch >= sample / kPhotonRebuildInterval) {
+            flush();
+            map = &maps[epoch % maps.size()];
         }
+        for (std::size_t k = 0; k < map->read.size(); ++k)
+            if (map->readRecorded[k]) {
+                hipOk(hipStreamWaitEvent(photonStream, map->read[k], 0));
+                map->readRecorded[k] = 0;
+            }
+        map->epoch = kNoEpoch;
+        currentMap = static_cast<std::uint32_t>(map - maps.data());
+        return *map;
+    }
+
+    void beginPhotonPass() {  // :742-745
+        reportOverflow(false);
+        launch.photonRadius = gatherRadius;
+        claimMap(nextEpoch());
+        launch.photonPass = nextEpoch();
+        hipOk(hipMemsetAsync(photonPool.at<void>(photonAt.counter), 0, sizeof(std::uint32_t), photonStream));
+    }
+
+    // The photon pass has wavefront state of its own, sized for a whole pass (at most 2^24 paths): every
+    // batch ends with the drain of its ray launches, so few large batches beat many frame-sized ones.
+    void ensurePhotonWavefront(std::uint32_t count) {
+        const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
+        if (photonWavefront && photonWavefrontCapacity >= wanted)
+            return;
+        hipOk(hipDeviceSynchronize());
+        if (photonWavefront)
+            rt_wavefront_destroy(photonWavefront);
+        photonWavefront = nullptr;
+        engineOk(rt_wavefront_create_for(wanted, RT_WAVEFRONT_FOR_PHOTONS, &photonWavefront), "rt_wavefront_create_for");
+        engineOk(rt_wavefront_set_light_index(photonWavefront, lightIndex, launch.lightCount), "rt_wavefront_set_light_index");
+        photonWavefrontCapacity = wanted;
+    }
+
+    // One range of a pass for a driver that merges the lists of several GPUs: waits for the tracer (not for
+    // the samples that are still rendering on other streams) and returns what this GPU stored (:746-769).
+    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {
+        ensurePhotonWavefront(count);
         rt_launch_params pass = launch;
         if (intoStaging)
-            pass.photons = photonPool.at<rt_photon>(photonAt.sorted);
-        engineOk(rt_trace_photons(photonWavefront, &pass, first, count, nullptr), "rt_trace_photons");
-        hipOk(hipDeviceSynchronize());
-        std::uint32_t stored = 0;
-        hipOk(hipMemcpy(&stored, photonPool.at<void>(photonAt.counter), sizeof(stored), hipMemcpyDeviceToHost));
+            pass.photons = photonPool.at<rt_photon>(maps[currentMap].sorted);
+        engineOk(rt_wavefront_set_photon_keys(photonWavefront, nullptr), "rt_wavefront_set_photon_keys");
+        engineOk(rt_trace_photons(photonWavefront, &pass, first, count, photonStream), "rt_trace_photons");
+        hipOk(hipMemcpyAsync(storedOnHost, photonPool.at<void>(photonAt.counter), sizeof(std::uint32_t), hipMemcpyDeviceToHost,
+                             photonStream));
+        hipOk(hipStreamSynchronize(photonStream));
+        const std::uint32_t stored = *storedOnHost;
+        warnIfOverfull(stored);
+        return std::min(stored, launch.photonCapacity);
+    }
+
+    void warnIfOverfull(std::uint32_t stored) {
         if (stored > launch.photonCapacity && !overflowReported) {
             overflowReported = true;  // once, like renderer.cpp:762-768
             std::fprintf(stderr, "warning: photon buffer full (%u of %u stored); the caustic will be darker than it should be\n",
                          stored, launch.photonCapacity);
         }
-        return std::min(stored, launch.photonCapacity);
     }
 
     void finishPhotonPass(std::uint32_t stored) {  // :770-776
         stored = std::min(stored, launch.photonCapacity);
-        engineOk(buildPhotonGrid(photonPool.at<const Photon>(photonAt.photons), stored, launch.photonRadius,
-                                 launch.photonBucketCount, photonPool.at<std::uint32_t>(photonAt.cellCounts),
-                                 photonPool.at<std::uint32_t>(photonAt.cellStart), photonPool.at<void>(photonAt.scan),
-                                 photonAt.scanBytes, photonPool.at<Photon>(photonAt.sorted)),
+        PhotonMap& map = maps[currentMap];
+        engineOk(rt_build_photon_grid_async(launch.photons, stored, launch.photonRadius, launch.photonBucketCount,
+                                            photonPool.at<std::uint32_t>(photonAt.cellCounts),
+                                            photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
+                                            photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted), photonStream),
                  "buildPhotonGrid");
-        engineOk(rt_photon_bucket_bitmap(photonPool.at<const std::uint32_t>(photonAt.cellStart), launch.photonBucketCount,
-                                         photonPool.at<std::uint32_t>(photonAt.bucketBits), nullptr),
-                 "rt_photon_bucket_bitmap");
-        ++launch.photonPass;
-        photonPassPending = false;
+        sealMap(map);
     }
 
-    bool photonPassDue() const {  // renderer.cpp:780
-        return launch.photonRadius > 0.0f && (sample + pending) % kPhotonRebuildInterval == 0U;
+    // Bucket bits of a freshly built map, the event its readers wait for, and the group it now serves.
+    void sealMap(PhotonMap& map) {
+        engineOk(rt_photon_bucket_bitmap(photonPool.at<const std::uint32_t>(map.cellStart), launch.photonBucketCount,
+                                         photonPool.at<std::uint32_t>(map.bucketBits), photonStream),
+                 "rt_photon_bucket_bitmap");
+        hipOk(hipEventRecord(map.built, photonStream));
+        map.epoch = launch.photonPass;
+    }
+
+    // The whole pass of renderer.cpp:741-777 without a wait: the reference synchronises behind the tracer and
+    // reads the stored count back (:753-758) to clamp it (:769) and hand it to the grid build (:770-775); here the
+    // count stays in device memory, the build reads and clamps it there, the tracer writes every photon's bucket
+    // key beside it, and the warning of :762-768 is printed when a copy of the count has reached the host by
+    // itself.  The host runs on to the samples that read the new map.
+    void photonPassInFlight() {
+        beginPhotonPass();
+        PhotonMap& map = maps[currentMap];
+        ensurePhotonWavefront(launch.photonEmissions);
+        engineOk(rt_wavefront_set_photon_keys(photonWavefront, photonKeys), "rt_wavefront_set_photon_keys");
+        engineOk(rt_trace_photons(photonWavefront, &launch, 0, launch.photonEmissions, photonStream), "rt_trace_photons");
+        const std::uint32_t* counter = photonPool.at<const std::uint32_t>(photonAt.counter);
+        watchStoredCount(counter);
+        const std::uint32_t most = std::min(launch.photonCapacity, launch.photonEmissions);
+        engineOk(rt_build_photon_grid_counted(launch.photons, counter, most, launch.photonRadius, launch.photonBucketCount,
+                                              photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
+                                              photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted), photonKeys ? 1 : 0,
+                                              photonStream),
+                 "rt_build_photon_grid_counted");
+        sealMap(map);
+    }
+
+    void watchStoredCount(const std::uint32_t* counter) {
+        StoredCount* slot = nullptr;
+        for (StoredCount& candidate : storedCounts)
+            if (!candidate.pending)
+                slot = &candidate;
+        if (!slot) {
+            if (storedCounts.size() >= 16) {  // the host is many passes ahead: look at the oldest first
+                reportOverflow(true);
+                return watchStoredCount(counter);
+            }
+            storedCounts.emplace_back();
+            slot = &storedCounts.back();
+            hipOk(hipHostMalloc(reinterpret_cast<void**>(&slot->value), sizeof(std::uint32_t), hipHostMallocDefault));
+            hipOk(hipEventCreateWithFlags(&slot->arrived, hipEventDisableTiming));
+        }
+        hipOk(hipMemcpyAsync(slot->value, counter, sizeof(std::uint32_t), hipMemcpyDeviceToHost, photonStream));
+        hipOk(hipEventRecord(slot->arrived, photonStream));
+        slot->pending = true;
+    }
+
+    // Looks at the stored counts that have reached the host (all of them after `wait`).
+    void reportOverflow(bool wait) {
+        for (StoredCount& count : storedCounts) {
+            if (!count.pending)
+                continue;
+            if (wait)
+                hipOk(hipEventSynchronize(count.arrived));
+            else if (hipEventQuery(count.arrived) != hipSuccess)
+                continue;
+            count.pending = false;
+            warnIfOverfull(*count.value);
+        }
     }
 
     // ---- one sample (renderer.cpp:779-796) --------------------------------------------------------------
     void render(void* target) {
         if (photonPassDue()) {
-            flush();
-            if (!manualPhotonPasses) {
-                beginPhotonPass();
-                finishPhotonPass(tracePhotonRange(0, launch.photonEmissions, false));
-            } else if (photonPassPending) {
+            if (manualPhotonPasses)
                 raise("a photon pass is due: run beginPhotonPass/tracePhotonRange/finishPhotonPass");
-            }
+            photonPassInFlight();
         }
         if (parts.empty())
             ensureParts();  // sets the number of samples a pass takes
         pendingTarget = target;
         ++pending;
-        photonPassPending = true;
         // a caller's own target is written by the pass this call belongs to, so that pass goes out now
         if (pending >= batch || target)
             flush();
@@ -800,9 +981,31 @@ struct Renderer::Impl {
         // ones: work on the default stream before and after still orders against them.
         const std::uint32_t count = partCount;
         const std::uint32_t set = passes % depth, before = (passes + depth - 1U) % depth;
+        // the maps of the groups of four samples this pass covers, in order
+        std::vector<rt_photon_map> gathered;
+        std::vector<PhotonMap*> gatheredFrom;
+        if (launch.photonRadius > 0.0f) {
+            const std::uint32_t firstEpoch = sample / kPhotonRebuildInterval, lastEpoch = (sample + pending - 1U) / kPhotonRebuildInterval;
+            for (std::uint32_t epoch = firstEpoch; epoch <= lastEpoch; ++epoch) {
+                PhotonMap& map = maps[epoch % maps.size()];
+                if (map.epoch != epoch)
+                    raise("no photon map for the samples of this pass");
+                gathered.push_back(rt_photon_map{photonPool.at<const rt_photon>(map.sorted),
+                                                 photonPool.at<const std::uint32_t>(map.cellStart),
+                                                 photonPool.at<const std::uint32_t>(map.bucketBits)});
+                gatheredFrom.push_back(&map);
+            }
+            launch.sortedPhotons = gathered.front().sortedPhotons;
+            launch.photonCellStart = gathered.front().cellStart;
+        }
         auto partOf = [&](std::uint32_t k) -> Part& {
             Part& part = parts[set * count + k];
             engineOk(rt_wavefront_set_sample_batch(part.wavefront, pending, sampleStride), "rt_wavefront_set_sample_batch");
+            engineOk(rt_wavefront_set_photon_maps(part.wavefront, gathered.data(), static_cast<std::uint32_t>(gathered.size()),
+                                                  kPhotonRebuildInterval, sample % kPhotonRebuildInterval),
+                     "rt_wavefront_set_photon_maps");
+            for (PhotonMap* map : gatheredFrom)
+                hipOk(hipStreamWaitEvent(part.stream, map->built, 0));
             if (depth > 1U) {
                 // this region's previous sample was accumulated by the part of the set before this one
                 Part& previous = parts[before * count + k];
@@ -835,6 +1038,13 @@ struct Renderer::Impl {
                     part.recorded = false;  // nothing was enqueued, so nothing records the event
             }
         }
+        // the photon pass that overwrites one of these maps waits for the parts that gather from it
+        for (PhotonMap* map : gatheredFrom)
+            for (std::uint32_t k = 0; k < count; ++k) {
+                const std::size_t index = static_cast<std::size_t>(set) * count + k;
+                hipOk(hipEventRecord(map->read[index], parts[index].stream));
+                map->readRecorded[index] = 1;
+            }
         sample += pending;
         pending = 0;
         pendingTarget = nullptr;
@@ -883,25 +1093,57 @@ struct Renderer::Impl {
         partCapacity = capacity;
         // Passes in flight: what was asked for, else two - with passes of several samples a second pass is
         // enough to cover the end of the first, and the state it saves goes into larger passes (1080p: 16 x 2
-        // 1.95 ms per sample, 8 x 4 1.99) - or four with a photon map, where a pass is one sample.
-        depth = depthWanted ? depthWanted : (caustics ? 4U : 2U);
-        // samples per pass: what was asked for, else the most of 64, 32, ..., 1 whose state fits the budget
-        batch = batchWanted;
+        // 1.95 ms per sample, 8 x 4 1.99).
+        depth = depthWanted ? depthWanted : 2U;
+        // Samples per pass: what was asked for, else the most of 64, 32, ..., 1 whose state fits the budget - the
+        // lesser of kStateBudget and half of the device memory that is free now, priced with the engine's own
+        // figure for a state of that many paths.  With a photon map a pass holds at most kMapsPerPass groups of
+        // four samples, each gathering from its group's map.
+        batch = caustics ? std::min(batchWanted, kMapsPerPass * kPhotonRebuildInterval) : batchWanted;
         if (batch == 0) {
-            // with a photon map every fourth sample starts behind a pass that waits for the GPU, and four
-            // samples in flight between two passes beat one pass over the four (3.77 against 4.42 ms per
-            // sample of the 32-bounce profile, whose late bounces are launches of a few thousand rays)
-            batch = caustics ? 1U : 64U;
-            while (batch > 1 && capacity * count * depth * batch * kStateBytesPerPath > kStateBudget)
+            std::size_t freeBytes = 0, totalBytes = 0;
+            hipOk(hipMemGetInfo(&freeBytes, &totalBytes));
+            const std::uint64_t budget = std::min<std::uint64_t>(kStateBudget, freeBytes / 2U);
+            batch = caustics ? kMapsPerPass * kPhotonRebuildInterval : 64U;
+            while (batch > 1 && stateBytes(capacity * batch) * count * depth > budget)
                 batch /= 2;
         }
+        for (;;) {
+            try {
+                makeParts(capacity, count);
+                break;
+            } catch (const std::exception&) {
+                // a state that does not fit after all (memory taken by others in the meantime): half the pass
+                destroyParts();
+                (void)hipGetLastError();
+                if (batch == 1 || batchWanted != 0)
+                    throw;
+                batch /= 2;
+            }
+        }
+        if (maps.size() != mapsWanted() || (!maps.empty() && maps.front().read.size() != parts.size()))
+            allocateMaps(mapsWanted());
+        shareLightIndex();
+    }
+
+    // Device bytes of a camera state of `paths` paths, as the engine states them.
+    static std::uint64_t stateBytes(std::uint64_t paths) {
+        std::size_t bytes = 0;
+        engineOk(rt_wavefront_state_bytes(static_cast<std::uint32_t>(std::min<std::uint64_t>(paths, 0xffffffffULL)),
+                                          RT_WAVEFRONT_FOR_CAMERA, &bytes),
+                 "rt_wavefront_state_bytes");
+        return bytes;
+    }
+
+    void makeParts(std::uint64_t capacity, std::uint32_t count) {
         parts.resize(static_cast<std::size_t>(count) * depth);
         if (parts.size() > 1)
             pickStreams();
         for (Part& part : parts) {
             if (capacity * batch > 0xffffffffULL)
                 raise("sample batch: pixels x samples of a pass do not fit 32 bits");
-            engineOk(rt_wavefront_create(static_cast<std::uint32_t>(capacity * batch), &part.wavefront), "rt_wavefront_create");
+            engineOk(rt_wavefront_create_for(static_cast<std::uint32_t>(capacity * batch), RT_WAVEFRONT_FOR_CAMERA, &part.wavefront),
+                     "rt_wavefront_create_for");
             engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
             // a single part stays on the default stream; parts that run side by side take half the wave
             // slots per ray launch: two of them then trace side by side, each filling the slots the
@@ -914,7 +1156,6 @@ struct Renderer::Impl {
             if (depth > 1)
                 hipOk(hipEventCreateWithFlags(&part.accumulated, hipEventDisableTiming));
         }
-        shareBucketBits();
     }
 
     // One stream per part, chosen so that they run side by side.  A process has a few hardware queues
@@ -980,6 +1221,7 @@ std::vector<std::uint8_t> Renderer::pixels() const {  // renderer.cpp:881-886
     impl_->flush();
     std::vector<std::uint8_t> image(impl_->outputBytes);
     hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->outputOffset), image.size(), hipMemcpyDeviceToHost));
+    impl_->reportOverflow(false);
     return image;
 }
 
@@ -987,6 +1229,7 @@ std::vector<float> Renderer::linearPixels() const {  // renderer.cpp:893-899
     impl_->flush();
     std::vector<float> image(impl_->aovBytes / sizeof(float));
     hipOk(hipMemcpy(image.data(), impl_->framePool.at<void>(impl_->aovOffset[0]), impl_->aovBytes, hipMemcpyDeviceToHost));
+    impl_->reportOverflow(false);
     return image;
 }
 
@@ -1031,7 +1274,7 @@ std::uint32_t Renderer::tracePhotonRange(std::uint32_t firstEmission, std::uint3
     return impl_->tracePhotonRange(firstEmission, emissionCount, intoStaging);
 }
 void* Renderer::photonBuffer() const { return impl_->photonPool.at<void>(impl_->photonAt.photons); }
-void* Renderer::photonStagingBuffer() const { return impl_->photonPool.at<void>(impl_->photonAt.sorted); }
+void* Renderer::photonStagingBuffer() const { return impl_->photonPool.at<void>(impl_->maps[impl_->currentMap].sorted); }
 std::uint32_t Renderer::photonCapacity() const { return impl_->launch.photonCapacity; }
 std::uint32_t Renderer::photonEmissions() const { return impl_->launch.photonEmissions; }
 void Renderer::finishPhotonPass(std::uint32_t totalPhotons) { impl_->finishPhotonPass(totalPhotons); }
@@ -1060,7 +1303,7 @@ void Renderer::statistics(std::uint64_t out[8]) {
     for (auto& part : impl_->parts)
         add(part.wavefront, part.stream);
     if (impl_->photonWavefront)
-        add(impl_->photonWavefront, nullptr);
+        add(impl_->photonWavefront, impl_->photonStream);
 }
 
 void Renderer::setMeasurement(bool timeStages, bool countTraversal, bool gatherPerLane) {
@@ -1117,12 +1360,11 @@ void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
 }
 
 std::uint32_t Renderer::concurrentTiles() const { return impl_->partCount; }
-std::uint32_t Renderer::samplesInFlight() const {
-    return impl_->depthWanted ? impl_->depthWanted : (impl_->caustics ? 4U : 2U);
-}
+std::uint32_t Renderer::samplesInFlight() const { return impl_->depthWanted ? impl_->depthWanted : 2U; }
 void Renderer::synchronize() const {
     impl_->flush();
     hipOk(hipDeviceSynchronize());
+    impl_->reportOverflow(true);
 }
 const rt_launch_params& Renderer::launchParams() const { return impl_->launch; }
 float Renderer::causticRadius() const { return impl_->gatherRadius; }

@@ -216,3 +216,36 @@ def test_builds_on_two_streams_through_the_library_workspace(engine, oracle):
         offsets, srt = oracle.build_photon_grid(ph, 0.004, B)
         assert np.array_equal(u32(grid.offsets), offsets)
         assert np.array_equal(grid.sorted[:len(ph)].cpu().numpy().view(np.uint32), srt.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,capacity,B,cs", [(0, 1000, 1 << 8, 0.01), (1, 8193, 1 << 8, 0.01), (8192, 8192, 1 << 12, 0.004),
+                                              (20000, 300000, 1 << 22, 0.004), (70001, 70001, 1 << 10, 0.002),
+                                              (300001, 1 << 20, 1 << 16, 0.0015)])
+def test_grid_build_with_the_count_on_the_device(engine, oracle, n, capacity, B, cs):
+    """rt_build_photon_grid_counted: the list's length is a word in device memory, the launches are sized for the
+    capacity; offsets and sorted list equal the oracle's build of the first n photons.  Also with a count beyond
+    the capacity (cut there, renderer.cpp:769) and with the keys written by the caller."""
+    import torch
+    ph = workloads.caustic_photons(capacity, seed=capacity)
+    grid = engine.PhotonGrid(capacity, B)
+    count = torch.tensor([n], dtype=torch.int32, device="cuda")
+    grid.build_counted(dev(ph), count, cs)
+    offsets, srt = oracle.build_photon_grid(ph[:n], cs, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:n].cpu().numpy().view(np.uint32), srt.view(np.uint32))
+    # a tracer that wanted to store more than fits
+    count.fill_(capacity + 12345)
+    grid.build_counted(dev(ph), count, cs)
+    offsets, srt = oracle.build_photon_grid(ph, cs, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:capacity].cpu().numpy().view(np.uint32), srt.view(np.uint32))
+    # keys put in place by the caller
+    count.fill_(n)
+    keys = grid.keys_view(capacity)
+    keys.fill_(-1)
+    keys[:n] = engine.photon_keys(dev(ph[:n, :3]), cs, B)
+    grid.offsets.fill_(-1)
+    grid.build_counted(dev(ph), count, cs, keys_ready=True)
+    offsets, srt = oracle.build_photon_grid(ph[:n], cs, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:n].cpu().numpy().view(np.uint32), srt.view(np.uint32))

@@ -469,7 +469,7 @@ def test_concurrent_tiles_do_not_change_the_image(R):
     default = R.Renderer(scene, w, h)
     # the renderer's own choice: two passes in flight, four with the final profile (single-sample passes)
     assert (default.concurrent_tiles(), default.samples_in_flight()) == (1, 2)
-    assert R.Renderer(scene, w, h, R.FINAL).samples_in_flight() == 4
+    assert R.Renderer(scene, w, h, R.FINAL).samples_in_flight() == 2
     default.set_concurrent_tiles(1, 3)
     default.set_concurrent_tiles(1, 0)
     assert default.samples_in_flight() == 2
@@ -537,12 +537,14 @@ def test_sample_batches_do_not_change_the_image(R):
     scene = workloads.caustic_lab()
     w, h = 64, 40
     shots = []
-    for batch, depth in ((1, 1), (4, 1), (3, 2), (8, 4)):
+    # (a pass of more than four samples gathers from the map of each group of four it holds; passes of 6 start
+    # inside a group every other time; 0 is the renderer's own choice)
+    for batch, depth in ((1, 1), (4, 1), (3, 2), (8, 4), (16, 2), (6, 1), (6, 3), (32, 1), (0, 0)):
         r = R.Renderer(scene, w, h, 1)
         r.set_photon_budget(1 << 19, 1 << 18, 1 << 14)
         r.set_concurrent_tiles(1, depth)
         r.set_sample_batch(batch)
-        for _ in range(10):
+        for _ in range(23):
             r.render()
         r.synchronize()
         shots.append(np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]))
