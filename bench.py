@@ -67,6 +67,10 @@ def parse():
                         "many ranks there are, one included: a rehearsal of the N > 1 path on one GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-photon-bench", action="store_true")
+    p.add_argument("--no-extra-legs", action="store_true",
+                   help="leave out the caustic-lab and triangle-soup legs that ride along with the default line at N = 1")
+    p.add_argument("--soup-sizes", type=int, nargs="*", default=[1000000, 10000000, 100000000],
+                   help="triangle counts of the soup leg (a size that does not fit the free memory is left out)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
@@ -262,6 +266,222 @@ def cpu_gather_baseline(grid, qp, qn, radius, buckets, seconds):
                       f"{srt.shape[0]}-photon grid, the oracle's gather loop on {threads} std::thread workers, {cpu_s:.2f} s"}
 
 
+def run_workload(args, workload, steps, warmup, world, rank, wire):
+    """Builds the scene and its renderer, counts the traversal of one step, runs `warmup` untimed and `steps`
+    timed steps between barriers, then repeats the steps on one stream with every launch between HIP events.
+    Returns what the result line is made of."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import distributed as D
+    from raytracer_amd import renderer as R
+    from raytracer_amd import workloads  # noqa: F401
+    scene, profile = make_scene(workload)
+    budget = (1 << 24, 1 << 23, 1 << 22) if profile == R.FINAL else None
+    if world > 1 or args.shared:
+        # the ranks share every frame: bands of eight rows dealt out in turn, emission ranges per rank
+        shared = D.DistributedRenderer(scene, args.width, args.height, profile, photon_budget=budget, batch=args.batch)
+        renderer = shared.renderer
+        step = shared.render
+    else:
+        shared = None
+        renderer = R.Renderer(scene, args.width, args.height, profile)
+        if budget:
+            renderer.set_photon_budget(*budget)
+        if args.batch:
+            renderer.set_sample_batch(args.batch)
+        step = renderer.render
+
+    # traversal averages per ray (for the algorithmic byte count), outside the timed region
+    if profile == R.FINAL:
+        # sample 0 starts with a photon pass, whose rays the traversal counters do not see
+        step()
+        renderer.statistics()
+    renderer.set_measurement(count_traversal=True)
+    step()
+    c = renderer.statistics()
+    counted = np.array([c["extend_rays"] + c["shadow_rays"], c["nodes"], c["triangles"]], dtype=np.float64)
+    if world > 1:
+        t = torch.from_numpy(counted).to(wire)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        counted = t.cpu().numpy()
+    counted_rays = max(counted[0], 1.0)
+    nodes_per_ray = counted[1] / counted_rays
+    tris_per_ray = counted[2] / counted_rays
+    bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
+
+    renderer.set_concurrent_tiles(args.tiles, args.in_flight)
+    in_flight = renderer.samples_in_flight()  # 0 on the command line: the renderer's own choice
+    renderer.set_measurement(time_stages=False)
+    for _ in range(warmup):
+        step()
+    renderer.synchronize()
+    renderer.statistics()
+    if shared:
+        shared.exchanges.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    renderer.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = renderer.statistics()
+    rays = float(stats["extend_rays"] + stats["shadow_rays"])
+    exchanges = list(shared.exchanges) if shared else []
+
+    # once per image, not per sample: the bands of every rank into the full frame
+    tile_allgather_ms = None
+    if shared:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        frame = shared.gather_buffer(0)
+        torch.cuda.synchronize()
+        tile_allgather_ms = (time.perf_counter() - t1) * 1e3
+        assert frame.shape == (args.height, args.width, 4)
+
+    # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
+    # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
+    # bracketed by HIP events on the stream it runs on.
+    # the passes keep their number of samples: a launch here is a launch of the timed region, alone on the GPU
+    batch = renderer.sample_batch()
+    renderer.set_concurrent_tiles(1)
+    renderer.set_sample_batch(batch)
+    renderer.set_measurement(time_stages=True)
+    for _ in range(batch):
+        step()
+    renderer.stage_timings()
+    renderer.statistics()
+    staged_steps = max(batch, steps // batch * batch)  # whole passes
+    for _ in range(staged_steps):
+        step()
+    renderer.synchronize()
+    stages = renderer.stage_timings()
+    staged = renderer.statistics()
+    staged_rays = float(staged["extend_rays"] + staged["shadow_rays"])
+    per_rank = [rays]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device=wire)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(e[0].item()) for e in every]
+        total_rays, total_gathers = sum(per_rank), sum(float(e[1].item()) for e in every)
+    else:
+        total_rays, total_gathers = rays, float(stats["gather_queries"])
+
+    # one photon pass by itself (final profile on one GPU): trace of every emission, grid build, bucket bits
+    photon_pass_ms = stored_photons = None
+    if profile == R.FINAL and not shared:
+        renderer.synchronize()
+        renderer.set_manual_photon_passes(True)
+        while not renderer.photon_pass_due():
+            step()
+        renderer.synchronize()
+        t1 = time.perf_counter()
+        renderer.begin_photon_pass()
+        stored_photons = renderer.trace_photon_range(0, renderer.photon_emissions())
+        renderer.finish_photon_pass(stored_photons)
+        renderer.synchronize()
+        photon_pass_ms = (time.perf_counter() - t1) * 1e3
+    p = renderer.launch_params()
+    result = dict(scene=scene, photon_pass_ms=photon_pass_ms, stored_photons=stored_photons, scene_triangles=int(sum(scene["geometries"][g]["indices"].shape[0] for g, _ in scene["instances"])),
+                  instances=len(scene["instances"]), light_count=int(p.lightCount), profile=profile, shared=bool(shared),
+                  elapsed=elapsed, rays=rays, total_rays=total_rays, total_gathers=total_gathers, per_rank=per_rank,
+                  stats=stats, stages=stages, staged_steps=staged_steps, staged_rays=staged_rays, batch=batch,
+                  in_flight=in_flight, bytes_per_ray=bytes_per_ray, nodes_per_ray=nodes_per_ray, tris_per_ray=tris_per_ray,
+                  exchanges=exchanges, tile_allgather_ms=tile_allgather_ms)
+    renderer.close()
+    return result
+
+
+def caustic_lab_leg(args, wire):
+    """caustic-lab stand-in at 1080p, final profile (32 bounces, 2^24 emissions into at most 2^23 photons over 2^22
+    buckets before every fourth sample, renderer.cpp:177, 533-535) through the same measurement as the headline."""
+    import copy
+    mine = copy.copy(args)
+    mine.tiles, mine.batch, mine.in_flight = 1, None, 0
+    steps, warmup = 64, 32
+    m = run_workload(mine, "caustic-lab", steps, warmup, 1, 0, wire)
+    trace_ms, launches = m["stages"]["trace"]
+    achieved = m["staged_rays"] * m["bytes_per_ray"] / (trace_ms * 1e-3) / 1e9
+    return {
+        "workload": f"caustic-lab stand-in, {args.width}x{args.height}, final profile, photon pass before every fourth step",
+        "steps": steps, "warmup": warmup,
+        "ms_per_step": m["elapsed"] / steps * 1e3,
+        "mrays_per_s": m["total_rays"] / m["elapsed"] / 1e6,
+        "rays_per_step": m["total_rays"] / steps,
+        "gathers_per_s_in_frame": m["total_gathers"] / m["elapsed"],
+        "gather_queries_per_step": m["total_gathers"] / steps,
+        "photon_pass_ms": m["photon_pass_ms"],
+        "photons_stored_per_pass": m["stored_photons"],
+        "samples_per_pass": m["batch"], "passes_in_flight": m["in_flight"],
+        "stage_ms_per_step": {k: v[0] / m["staged_steps"] for k, v in m["stages"].items()},
+        "roofline": {"bound": "hbm", "kernel": "traceKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "bytes_per_ray": m["bytes_per_ray"],
+                     "nodes_per_ray": m["nodes_per_ray"], "triangles_per_ray": m["tris_per_ray"],
+                     "avg_launch_ms": trace_ms / max(launches, 1), "launches": launches},
+    }
+
+
+def soup_leg(eng, sizes, rays=1 << 24, repeats=3):
+    """Uniform triangle soups (centroids uniform in the unit cube, edge length ~ U(0.5, 1.5) n^(-1/3), drawn on the
+    GPU) and 2^24 incoherent closest-hit rays: build time of the bottom-level tree, Mrays/s, the ray kernel against
+    the HBM roofline by algorithmic bytes (52 B per ray + 80 B per node visited + 36 B per triangle tested)."""
+    import torch
+    out = []
+    for n in sizes:
+        need = n * (36 + 12 + 48 + 40) * 2 + rays * 64  # triangles, indices, packed copy, nodes and sort scratch; rays
+        if torch.cuda.mem_get_info()[0] < need + (8 << 30):
+            out.append({"triangles": n, "skipped": "not enough free device memory"})
+            continue
+        gen = torch.Generator(device="cuda").manual_seed(4)
+        centre = torch.rand((n, 1, 3), generator=gen, device="cuda")
+        size = (torch.rand((n, 1, 1), generator=gen, device="cuda") + 0.5) * n ** (-1.0 / 3.0)
+        corners = torch.randn((n, 3, 3), generator=gen, device="cuda")
+        corners /= corners.norm(dim=2, keepdim=True)
+        corners *= 0.5 * size
+        corners += centre
+        positions = corners.reshape(-1, 3).contiguous()
+        indices = torch.arange(3 * n, dtype=torch.int32, device="cuda").reshape(-1, 3)
+        del centre, size, corners
+        blas = eng.Blas(positions, indices)
+        top = eng.Scene([(blas, None)])
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        o = torch.rand((rays, 4), generator=gen, device="cuda") * 1.1 - 0.05
+        o[:, 3] = 0.001
+        d = torch.randn((rays, 4), generator=gen, device="cuda")
+        d[:, :3] /= d[:, :3].norm(dim=1, keepdim=True)
+        d[:, 3] = 1e16
+        counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+        top.trace_closest(o, d, counters=counters)
+        c = counters.cpu().numpy().astype(float)
+        hits, inst = top.trace_closest(o, d)
+        torch.cuda.synchronize()
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        begin.record()
+        for _ in range(repeats):
+            top.trace_closest(o, d, hits=hits, inst=inst)
+        end.record()
+        torch.cuda.synchronize()
+        ms = begin.elapsed_time(end) / repeats
+        nodes, tris = c[1] / c[0], c[2] / c[0]
+        per_ray = RAY_IO_BYTES + nodes * NODE_BYTES + tris * TRIANGLE_BYTES
+        gbs = rays * per_ray / (ms * 1e-3) / 1e9
+        out.append({"triangles": n, "rays": rays, "build_ms": float(blas.stats().buildMilliseconds),
+                    "mrays_per_s": rays / (ms * 1e-3) / 1e6, "launch_ms": ms, "nodes_per_ray": nodes,
+                    "triangles_per_ray": tris, "bytes_per_ray": per_ray, "frac": gbs / HBM_PEAK_GBS,
+                    "achieved_gbs": gbs})
+        del top, blas, positions, indices, o, d, hits, inst
+        torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(args):
     """Starts args.gpus ranks of this script as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
     their environment, as torch.distributed.run would set them), relays rank 0's stdout (the one JSON line) to
@@ -345,106 +565,20 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     R.load()
+    m = run_workload(args, args.workload, args.steps, args.warmup, world, rank, wire)
+    profile, shared = m["profile"], m["shared"]
+    elapsed, rays, total_rays, total_gathers, per_rank = m["elapsed"], m["rays"], m["total_rays"], m["total_gathers"], m["per_rank"]
+    stats, stages, staged_steps, staged_rays = m["stats"], m["stages"], m["staged_steps"], m["staged_rays"]
+    batch, in_flight, exchanges, tile_allgather_ms = m["batch"], m["in_flight"], m["exchanges"], m["tile_allgather_ms"]
+    bytes_per_ray, nodes_per_ray, tris_per_ray = m["bytes_per_ray"], m["nodes_per_ray"], m["tris_per_ray"]
 
-    scene, profile = make_scene(args.workload)
-    budget = (1 << 24, 1 << 23, 1 << 22) if profile == R.FINAL else None
-    if world > 1 or args.shared:
-        # the ranks share every frame: bands of eight rows dealt out in turn, emission ranges per rank
-        shared = D.DistributedRenderer(scene, args.width, args.height, profile, photon_budget=budget, batch=args.batch)
-        renderer = shared.renderer
-        step = shared.render
-    else:
-        shared = None
-        renderer = R.Renderer(scene, args.width, args.height, profile)
-        if budget:
-            renderer.set_photon_budget(*budget)
-        if args.batch:
-            renderer.set_sample_batch(args.batch)
-        step = renderer.render
-
-    # traversal averages per ray (for the algorithmic byte count), outside the timed region
-    if profile == R.FINAL:
-        # sample 0 starts with a photon pass, whose rays the traversal counters do not see
-        step()
-        renderer.statistics()
-    renderer.set_measurement(count_traversal=True)
-    step()
-    c = renderer.statistics()
-    counted = np.array([c["extend_rays"] + c["shadow_rays"], c["nodes"], c["triangles"]], dtype=np.float64)
-    if world > 1:
-        t = torch.from_numpy(counted).to(wire)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        counted = t.cpu().numpy()
-    counted_rays = max(counted[0], 1.0)
-    nodes_per_ray = counted[1] / counted_rays
-    tris_per_ray = counted[2] / counted_rays
-    bytes_per_ray = RAY_IO_BYTES + nodes_per_ray * NODE_BYTES + tris_per_ray * TRIANGLE_BYTES
-
-    renderer.set_concurrent_tiles(args.tiles, args.in_flight)
-    in_flight = renderer.samples_in_flight()  # 0 on the command line: the renderer's own choice
-    renderer.set_measurement(time_stages=False)
-    for _ in range(args.warmup):
-        step()
-    renderer.synchronize()
-    renderer.statistics()
-    if shared:
-        shared.exchanges.clear()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    renderer.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    stats = renderer.statistics()
-    rays = float(stats["extend_rays"] + stats["shadow_rays"])
-    exchanges = list(shared.exchanges) if shared else []
-
-    # once per image, not per sample: the bands of every rank into the full frame
-    tile_allgather_ms = None
-    if shared:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        frame = shared.gather_buffer(0)
-        torch.cuda.synchronize()
-        tile_allgather_ms = (time.perf_counter() - t1) * 1e3
-        assert frame.shape == (args.height, args.width, 4)
-
-    # Per-stage kernel time, outside the timed region: the same number of steps on one stream (the
-    # parts of a tiled frame overlap in time, which would count the overlap twice), every launch
-    # bracketed by HIP events on the stream it runs on.
-    # the passes keep their number of samples: a launch here is a launch of the timed region, alone on the GPU
-    batch = renderer.sample_batch()
-    renderer.set_concurrent_tiles(1)
-    renderer.set_sample_batch(batch)
-    renderer.set_measurement(time_stages=True)
-    for _ in range(batch):
-        step()
-    renderer.stage_timings()
-    renderer.statistics()
-    staged_steps = max(batch, args.steps // batch * batch)  # whole passes
-    for _ in range(staged_steps):
-        step()
-    renderer.synchronize()
-    stages = renderer.stage_timings()
-    staged = renderer.statistics()
-    staged_rays = float(staged["extend_rays"] + staged["shadow_rays"])
-    per_rank = [rays]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = torch.tensor([rays, float(stats["gather_queries"])], dtype=torch.float64, device=wire)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank = [float(e[0].item()) for e in every]
-        total_rays, total_gathers = sum(per_rank), sum(float(e[1].item()) for e in every)
-    else:
-        total_rays, total_gathers = rays, float(stats["gather_queries"])
+    # Beside the headline, outside its timed region and at N = 1 only: the other workload north_star names
+    # (caustic-lab, final profile, photon map at the reference's sizes) and the triangle soups of the last
+    # configuration, whose build time is a reported metric.
+    legs = {}
+    if world == 1 and not args.shared and not args.no_extra_legs and args.workload == "dragon-cornell":
+        legs["caustic_lab"] = caustic_lab_leg(args, wire)
+        legs["soup"] = soup_leg(eng, args.soup_sizes)
 
     photon = None
     if not args.no_photon_bench:
@@ -461,7 +595,6 @@ def main():
     traffic = profiled_traffic() if profiled_workload else None
     achieved = staged_rays * bytes_per_ray / (trace_ms * 1e-3) / 1e9
     avg_launch_s = trace_ms * 1e-3 / max(trace_launches, 1)
-    p = renderer.launch_params()
     if shared:
         parallelism = (f"replicated scene; one frame shared by {world} ranks, bands of 8 pixel rows dealt out in turn"
                        + ("; photon emission ranges per rank, lists exchanged rank to rank over RCCL every 4th step"
@@ -489,9 +622,9 @@ def main():
             "rays_per_step_per_gpu": rays / args.steps,
             "extend_rays_per_step": stats["extend_rays"] / args.steps,
             "shadow_rays_per_step": stats["shadow_rays"] / args.steps,
-            "triangles": int(sum(scene["geometries"][g]["indices"].shape[0] for g, _ in scene["instances"])),
-            "instances": len(scene["instances"]),
-            "light_count": int(p.lightCount),
+            "triangles": m["scene_triangles"],
+            "instances": m["instances"],
+            "light_count": m["light_count"],
             "parallelism": parallelism,
         },
         "stage_ms_per_step": {k: v[0] / staged_steps for k, v in stages.items()},
@@ -540,8 +673,13 @@ def main():
     if photon is not None:
         out["photon_gathers_per_s"] = photon["gathers_per_s"]
         out["photon"] = photon
+    if m["photon_pass_ms"] is not None:
+        out["photon_pass_ms"] = m["photon_pass_ms"]
+        out["photons_stored_per_pass"] = m["stored_photons"]
+    if legs:
+        out.update(legs)
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(scene, args, args.width, args.height, profile)
+        out["cpu_baseline"] = cpu_baseline(m["scene"], args, args.width, args.height, profile)
         if photon is not None and photon.get("cpu_baseline"):
             out["cpu_baseline"]["gather"] = photon.pop("cpu_baseline")
     if photon is not None:
