@@ -17,8 +17,10 @@
 #include "radix_sort.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 // Whether node slots left over by the collapse are spent on splitting leaves.
@@ -757,74 +759,99 @@ struct HostBox {
 // Binary tree over the clusters by top-down binned surface-area splits.  Nodes come out in
 // pre-order (the root first), which is also the order the old upper nodes' ids are handed to
 // them in; a child reference is either an index into `nodes` or, with kClusterBit, a cluster.
+//
+// A subtree over m clusters has m - 1 nodes, so the pre-order position of every node follows
+// from the sizes of the ranges alone: the node of a range sits at `base`, its left subtree
+// behind it, its right subtree behind that.  Subtrees therefore write disjoint parts of
+// `nodes` and `order`, and the first levels hand their halves to threads of their own; the
+// tree is the same whatever the number of threads.
 struct UpperBuilder {
     static constexpr int kBins = 16;
     static constexpr uint32_t kClusterBit = 0x80000000U;
+    static constexpr uint32_t kForkLevels = 3, kForkMinimum = 512;  // up to eight threads, none for small ranges
     struct Node {
         HostBox box;
         uint32_t left, right, triangles;
     };
     const std::vector<ClusterRecord>& clusters;
     std::vector<HostBox> boxes;
-    std::vector<uint32_t> order;
+    std::vector<float> centre[3];
+    std::vector<uint32_t> order, scratch;
     std::vector<Node> nodes;
+    // A cut that leaves one side with less than this share of a range's clusters is replaced by the median
+    // cut: a chain of lopsided cuts is what makes a tree deep, and the traversal stack is finite.
+    static constexpr uint32_t kLopsided = 16;
 
-    explicit UpperBuilder(const std::vector<ClusterRecord>& c) : clusters(c), boxes(c.size()), order(c.size()) {
+    explicit UpperBuilder(const std::vector<ClusterRecord>& c)
+        : clusters(c), boxes(c.size()), order(c.size()), scratch(c.size()), nodes(c.empty() ? 0 : c.size() - 1) {
+        for (auto& axis : centre)
+            axis.resize(c.size());
         for (size_t i = 0; i < c.size(); ++i) {
             boxes[i] = {{c[i].box.lo.x, c[i].box.lo.y, c[i].box.lo.z}, {c[i].box.hi.x, c[i].box.hi.y, c[i].box.hi.z}};
+            for (int a = 0; a < 3; ++a)
+                centre[a][i] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
             order[i] = static_cast<uint32_t>(i);
         }
-        nodes.reserve(c.size());
     }
 
-    // Builds the subtree over order[begin, end) and returns its reference.
-    uint32_t build(uint32_t begin, uint32_t end) {
+    uint32_t build(uint32_t begin, uint32_t end) { return build(begin, end, 0U, 0U); }
+
+    // Builds the subtree over order[begin, end), whose node goes to nodes[base], and returns its reference.
+    uint32_t build(uint32_t begin, uint32_t end, uint32_t base, uint32_t level) {
         if (end - begin == 1U)
             return kClusterBit | order[begin];
-        HostBox all = HostBox::empty(), centres = HostBox::empty();
+        HostBox all = HostBox::empty();
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t triangles = 0;
         for (uint32_t i = begin; i < end; ++i) {
-            const HostBox& b = boxes[order[i]];
-            all.grow(b);
+            const uint32_t c = order[i];
+            all.grow(boxes[c]);
             for (int a = 0; a < 3; ++a) {
-                const float c = 0.5f * (b.lo[a] + b.hi[a]);
-                centres.lo[a] = std::min(centres.lo[a], c);
-                centres.hi[a] = std::max(centres.hi[a], c);
+                lo[a] = std::min(lo[a], centre[a][c]);
+                hi[a] = std::max(hi[a], centre[a][c]);
             }
-            triangles += clusters[order[i]].triangles;
+            triangles += clusters[c].triangles;
+        }
+        // the three axes are binned in one pass over the range
+        HostBox binBox[3][kBins];
+        uint32_t binCount[3][kBins] = {};
+        float scale[3];
+        bool usable[3];
+        for (int a = 0; a < 3; ++a) {
+            usable[a] = hi[a] - lo[a] > 0.0f;
+            scale[a] = usable[a] ? static_cast<float>(kBins) / (hi[a] - lo[a]) : 0.0f;
+            for (auto& b : binBox[a])
+                b = HostBox::empty();
+        }
+        for (uint32_t i = begin; i < end; ++i) {
+            const uint32_t c = order[i];
+            for (int a = 0; a < 3; ++a)
+                if (usable[a]) {
+                    const int bin = binOf(centre[a][c], lo[a], scale[a]);
+                    binBox[a][bin].grow(boxes[c]);
+                    binCount[a][bin] += clusters[c].triangles;
+                }
         }
         int bestAxis = -1, bestBin = 0;
         float bestCost = INFINITY;
         for (int axis = 0; axis < 3; ++axis) {
-            const float extent = centres.hi[axis] - centres.lo[axis];
-            if (!(extent > 0.0f))
+            if (!usable[axis])
                 continue;
-            HostBox binBox[kBins];
-            uint32_t binCount[kBins] = {};
-            for (auto& b : binBox)
-                b = HostBox::empty();
-            const float scale = static_cast<float>(kBins) / extent;
-            for (uint32_t i = begin; i < end; ++i) {
-                const HostBox& b = boxes[order[i]];
-                const int bin = binOf(b, axis, centres.lo[axis], scale);
-                binBox[bin].grow(b);
-                binCount[bin] += clusters[order[i]].triangles;
-            }
             float rightArea[kBins];
             uint32_t rightCount[kBins];
             HostBox run = HostBox::empty();
             uint32_t count = 0;
             for (int k = kBins - 1; k >= 1; --k) {
-                run.grow(binBox[k]);
-                count += binCount[k];
+                run.grow(binBox[axis][k]);
+                count += binCount[axis][k];
                 rightArea[k] = run.area();
                 rightCount[k] = count;
             }
             run = HostBox::empty();
             count = 0;
             for (int k = 1; k < kBins; ++k) {  // cut between bin k - 1 and bin k
-                run.grow(binBox[k - 1]);
-                count += binCount[k - 1];
+                run.grow(binBox[axis][k - 1]);
+                count += binCount[axis][k - 1];
                 if (count == 0U || rightCount[k] == 0U)
                     continue;
                 const float cost = run.area() * static_cast<float>(count) + rightArea[k] * static_cast<float>(rightCount[k]);
@@ -837,26 +864,42 @@ struct UpperBuilder {
         }
         uint32_t middle = begin + (end - begin) / 2U;
         if (bestAxis >= 0) {
-            const float lo = centres.lo[bestAxis];
-            const float scale = static_cast<float>(kBins) / (centres.hi[bestAxis] - lo);
-            auto split = std::stable_partition(order.begin() + begin, order.begin() + end, [&](uint32_t c) {
-                return binOf(boxes[c], bestAxis, lo, scale) < bestBin;
-            });
-            middle = static_cast<uint32_t>(split - order.begin());
-            if (middle == begin || middle == end)
-                middle = begin + (end - begin) / 2U;
+            // stable partition through the scratch array (this range's part of it)
+            uint32_t left = begin, right = 0;
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t c = order[i];
+                if (binOf(centre[bestAxis][c], lo[bestAxis], scale[bestAxis]) < bestBin)
+                    order[left++] = c;
+                else
+                    scratch[begin + right++] = c;
+            }
+            const uint32_t size = end - begin, smaller = std::min(left - begin, right);
+            if (smaller != 0U && static_cast<uint64_t>(smaller) * kLopsided >= size) {
+                std::copy(scratch.begin() + begin, scratch.begin() + begin + right, order.begin() + left);
+                middle = left;
+            } else {
+                // the median of the range in the order it has now (left part, then right part)
+                std::copy(scratch.begin() + begin, scratch.begin() + begin + right, order.begin() + left);
+            }
         }
-        const uint32_t self = static_cast<uint32_t>(nodes.size());
-        nodes.push_back({all, 0U, 0U, triangles});
-        const uint32_t l = build(begin, middle);
-        const uint32_t r = build(middle, end);
-        nodes[self].left = l;
-        nodes[self].right = r;
-        return self;
+        nodes[base].box = all;
+        nodes[base].triangles = triangles;
+        const uint32_t leftBase = base + 1U, rightBase = base + (middle - begin);
+        uint32_t l, r;
+        if (level < kForkLevels && end - begin >= kForkMinimum) {
+            std::thread other([&] { l = build(begin, middle, leftBase, level + 1U); });
+            r = build(middle, end, rightBase, level + 1U);
+            other.join();
+        } else {
+            l = build(begin, middle, leftBase, level + 1U);
+            r = build(middle, end, rightBase, level + 1U);
+        }
+        nodes[base].left = l;
+        nodes[base].right = r;
+        return base;
     }
 
-    static int binOf(const HostBox& b, int axis, float lo, float scale) {
-        const float c = 0.5f * (b.lo[axis] + b.hi[axis]);
+    static int binOf(float c, float lo, float scale) {
         const int bin = static_cast<int>((c - lo) * scale);
         return bin < 0 ? 0 : (bin >= kBins ? kBins - 1 : bin);
     }
@@ -867,6 +910,17 @@ struct UpperBuilder {
 rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, DeviceBuffer& right, DeviceBuffer& parent,
                             DeviceBuffer& first, DeviceBuffer& last, DeviceBuffer& bounds, DeviceBuffer& counts,
                             DeviceBuffer& partials, const uint32_t*& order, uint32_t* spareOrder) {
+    // RT_BLAS_TIMING=1 prints where the time of this step goes (host clock, the stream waited for at each mark)
+    const bool timing = std::getenv("RT_BLAS_TIMING") != nullptr;
+    auto clock = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing)
+            return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  refine %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - clock).count());
+        clock = now;
+    };
     // about this many clusters (RT_BLAS_CLUSTERS overrides): the host's share of the build grows with it
     uint32_t targetClusters = 8192;
     if (const char* v = std::getenv("RT_BLAS_CLUSTERS"))
@@ -888,6 +942,7 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
     RT_HIP(hipMemcpyAsync(&clusterCount, marks.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RT_HIP(hipMemcpyAsync(&upperCount, upper.as<uint32_t>() + (n - 1U), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RT_HIP(hipStreamSynchronize(stream));
+    mark("cluster cut + counts");
     if (clusterCount < 2U)
         return RT_SUCCESS;  // the whole tree is one cluster
     if (upperCount + 1U != clusterCount)
@@ -906,11 +961,13 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
     RT_HIP(hipStreamSynchronize(stream));
     if (ids.empty() || ids[0] != 0U)
         return failInvalid("the root is not among the upper nodes");
+    mark("clusters to the host");
 
     UpperBuilder builder(clusters);
     builder.build(0, clusterCount);
     if (builder.nodes.size() != upperCount)
         return failInvalid("upper tree has the wrong size");
+    mark("surface-area build (host)");
     auto reference = [&](uint32_t r) {
         return (r & UpperBuilder::kClusterBit) ? clusters[r & ~UpperBuilder::kClusterBit].node : ids[r];
     };
@@ -944,6 +1001,7 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
     RT_HIP(hipMemcpyAsync(bounds.as<Box4>() + (n - 1U), leafBounds.data, sizeof(Box4) * n, hipMemcpyDeviceToDevice, stream));
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(stream));  // the scratch buffers of this function go out of scope
+    mark("scatter + leaf order");
     order = spareOrder;
     return RT_SUCCESS;
 }
@@ -1570,17 +1628,23 @@ void rt_scene_destroy(rt_scene* scene) {
 rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* records, uint32_t count) {
     if (!scene || !records || count == 0)
         return failInvalid("null pointer");
-    if (scene->hitGroups) {
-        RT_HIP(hipFree(scene->hitGroups));
-        scene->hitGroups = nullptr;
-    }
+    // nothing of the scene changes before the new records are known to be good and in place
     for (const ShadeInstance& si : scene->shadeHost)
         if (si.geometry >= count) {
             setLastError("an instance refers to a geometry beyond the records given");
             return RT_ERROR_OUT_OF_RANGE;
         }
-    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->hitGroups), sizeof(rt_hit_group_data) * count));
-    RT_HIP(hipMemcpy(scene->hitGroups, records, sizeof(rt_hit_group_data) * count, hipMemcpyHostToDevice));
+    rt_hit_group_data* fresh = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), sizeof(rt_hit_group_data) * count));
+    const hipError_t copied = hipMemcpy(fresh, records, sizeof(rt_hit_group_data) * count, hipMemcpyHostToDevice);
+    if (copied != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(copied, "hipMemcpy (hit-group records)");
+    }
+    // launches that still read the old records or the shading table finish first
+    RT_HIP(hipDeviceSynchronize());
+    rt_hit_group_data* old = scene->hitGroups;
+    scene->hitGroups = fresh;
     scene->hitGroupCount = count;
     // every instance carries its geometry's record
     for (ShadeInstance& si : scene->shadeHost) {
@@ -1590,6 +1654,8 @@ rt_status rt_scene_set_geometry(rt_scene* scene, const rt_hit_group_data* record
     }
     RT_HIP(hipMemcpy(scene->shadeInstances, scene->shadeHost.data(), sizeof(ShadeInstance) * scene->shadeHost.size(),
                      hipMemcpyHostToDevice));
+    if (old)
+        (void)hipFree(old);
     return RT_SUCCESS;
 }
 

@@ -43,6 +43,13 @@ struct LightIndex {
     uint32_t mask = 0;                            // capacity - 1
 };
 
+// A word that names the light array an index was built from (its address folded to 32 bits): the launches
+// compare it with the array of their parameters and walk the list when it is another one.
+__host__ __device__ inline uint32_t lightArrayTag(const void* lights) {
+    const unsigned long long address = reinterpret_cast<unsigned long long>(lights);
+    return static_cast<uint32_t>(address ^ (address >> 32)) | 1U;
+}
+
 __host__ __device__ inline uint32_t lightTableCapacity(uint32_t lightCount) {
     uint32_t capacity = 2;
     while (capacity < 2U * lightCount && capacity < 0x80000000U)

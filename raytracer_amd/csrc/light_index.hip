@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kBlock) void lightIndexClearKernel(const rt_gpu_lig
         words[0] = count;
         words[1] = capacity;
         words[2] = withThresholds;
-        words[3] = 0;
+        words[3] = lightArrayTag(lights);  // which array the index describes (rt_wavefront_set_light_index)
         if (aligned != head)
             words[head] = 0;
     }

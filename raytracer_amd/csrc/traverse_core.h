@@ -410,8 +410,10 @@ struct Traversal {
         // below: its plane distances are 0 * inf or inf - inf, the NaN that fmaxf / fminf drop.  That is
         // safe but lets the ray into every child along the axis - a hundred times the visits of its
         // neighbours, alone in its wave.  Such a ray can only enter a child whose slab holds its origin,
-        // which is tested on the planes themselves.  The difference below is rounded, but towards the
-        // plane it is compared with, never across it: a child is only dropped when the origin is outside.
+        // which is tested on the planes themselves, with a margin: corner - origin and the multiply-add are two
+        // roundings, so a child is only dropped when the origin is outside its slab by more than 2^-20 of the
+        // magnitudes involved (the margin the general path gives its boxes); an origin on a plane, or within
+        // rounding of it, keeps the child.
         if ((cur.dx * cur.dy) * cur.dz == 0.0f) {
             auto outsideSlab = [&](float direction, float origin, uint32_t corner, uint32_t exponent, uint32_t lo0,
                                    uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint32_t {
@@ -419,13 +421,14 @@ struct Traversal {
                     return 0U;
                 const float scale = __uint_as_float((exponent & 0xffU) << 23);
                 const float offset = __uint_as_float(corner) - origin;
+                const float margin = 0x1p-20f * ((fabsf(__uint_as_float(corner)) + fabsf(origin)) + 255.0f * scale);
                 uint32_t outside = 0U;
 #pragma unroll
                 for (int i = 0; i < kWide; ++i) {
                     const int sh = 8 * (i & 3);
                     const float qlo = static_cast<float>(((i < 4 ? lo0 : lo1) >> sh) & 0xffU);
                     const float qhi = static_cast<float>(((i < 4 ? hi0 : hi1) >> sh) & 0xffU);
-                    if (fmaf(qlo, scale, offset) > 0.0f || fmaf(qhi, scale, offset) < 0.0f)
+                    if (fmaf(qlo, scale, offset) > margin || fmaf(qhi, scale, offset) < -margin)
                         outside |= 1U << i;
                 }
                 return outside;

@@ -961,6 +961,7 @@ struct rt_wavefront {
     std::vector<void*> allocations;
     uint32_t* scanCounts = nullptr;    // capacity + 1
     uint32_t* photonKeys = nullptr;    // bucket keys of stored photons go here too (rt_wavefront_set_photon_keys)
+    uint32_t lightIndexTag = 0;        // names the light array the index was built from
     rt::PhotonMaps photonMaps{};       // the maps of the next pass (rt_wavefront_set_photon_maps); count 0: the parameters' map
     uint32_t uses = RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS;
     uint32_t* scanPartials = nullptr;
@@ -1067,6 +1068,10 @@ rt_status rt_wavefront_create_for(uint32_t maxPaths, uint32_t uses, rt_wavefront
         }
         w->allocations.push_back(raw);
         pointer = static_cast<T*>(raw);
+        // development aid: RT_WAVEFRONT_POISON=<byte> fills every array, so that a read of something never
+        // written shows up as a changed image instead of depending on what the allocator handed out
+        if (const char* poison = std::getenv("RT_WAVEFRONT_POISON"))
+            (void)hipMemset(raw, std::atoi(poison) & 0xff, sizeof(T) * count);
     });
     Buffers& b = w->buffers;
     b.capacity = maxPaths;
@@ -1180,6 +1185,7 @@ rt_status rt_wavefront_set_light_index(rt_wavefront* w, const void* index, uint3
     if (header[0] != lightCount || header[1] != rt::lightTableCapacity(lightCount))
         return failInvalid("the light index was built for another light count");
     w->buffers.lightIndex = rt::lightIndexView(index, lightCount, header[2] != 0U);
+    w->lightIndexTag = header[3];
     return RT_SUCCESS;
 }
 
@@ -1239,6 +1245,16 @@ struct StageTimer {
 };
 
 }  // namespace
+
+// The state's buffers for a launch with these parameters: the light index only describes the light array it
+// was built from; for parameters that carry another array (or another count) the launch walks the list, which
+// gives the reference's choice whatever the list.
+static Buffers buffersFor(const rt_wavefront* w, const rt_launch_params* params) {
+    Buffers b = w->buffers;
+    if (b.lightIndex.count != params->lightCount || w->lightIndexTag != lightArrayTag(params->lights))
+        b.lightIndex = LightIndex{};
+    return b;
+}
 
 // Array sizes the ray stage checks references against: top-level nodes, instances.
 static uint2 limitsOf(const rt_scene* scene) {
@@ -1306,7 +1322,7 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
         return failInvalid("pixels x samples of the batch larger than the wavefront capacity");
     map.count = map.perSample * map.samples;
     const uint32_t count = map.count;
-    const Buffers& b = w->buffers;
+    const Buffers b = buffersFor(w, params);
     if (!(w->uses & RT_WAVEFRONT_FOR_CAMERA))
         return failInvalid("this wavefront state was created for photon passes only");
     PhotonMaps photonMaps = w->photonMaps;
@@ -1444,7 +1460,7 @@ rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint
     if (!(w->uses & RT_WAVEFRONT_FOR_PHOTONS))
         return failInvalid("this wavefront state was created for camera passes only");
     auto s = static_cast<hipStream_t>(stream);
-    const Buffers& b = w->buffers;
+    const Buffers b = buffersFor(w, params);
     uint32_t* keys = w->photonKeys;
     if (keys && (!(params->photonRadius > 0.0f) || params->photonBucketCount == 0 ||
                  (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))

@@ -42,10 +42,11 @@ def test_one_json_line_with_the_contract_fields():
     assert cpu["kind"] == "port" and cpu["unit"] == "Mrays/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert cpu["gather"]["unit"] == "gathers/s" and cpu["gather"]["value"] > 0
     assert line["photon_gathers_per_s"] > 0
-    # the legs that ride along: the final-profile workload and the triangle soup
+    # the legs that ride along: the final-profile workload and the triangle soup (the lab's 5,890 triangles live in
+    # the caches, so its algorithmic bytes per second are no physical bound and can pass the HBM peak)
     lab = line["caustic_lab"]
     assert lab["ms_per_step"] > 0 and lab["mrays_per_s"] > 0 and lab["gathers_per_s_in_frame"] > 0
-    assert lab["photon_pass_ms"] > 0 and lab["photons_stored_per_pass"] > 0 and 0 < lab["roofline"]["frac"] < 1.5
+    assert lab["photon_pass_ms"] > 0 and lab["photons_stored_per_pass"] > 0 and lab["roofline"]["frac"] > 0
     assert abs(lab["mrays_per_s"] - lab["rays_per_step"] / lab["ms_per_step"] / 1e3) < 1e-6 * lab["mrays_per_s"]
     (soup,) = line["soup"]
     assert soup["triangles"] == 100000 and soup["build_ms"] > 0 and soup["mrays_per_s"] > 0 and 0 < soup["frac"] < 1

@@ -157,3 +157,51 @@ def test_render_with_forty_thousand_emissive_triangles(engine, oracle, monkeypat
     assert close > 0.97, close
     keep = cpu[:, :3].max(axis=1) < np.percentile(cpu[:, :3].max(axis=1), 99.5)
     assert rel_rmse(image[keep, :3], cpu[keep, :3]) < 5e-2
+
+
+def test_an_index_of_another_light_array_is_not_used(engine):
+    """A wavefront state keeps the light index it was given; launch parameters whose light array is another one
+    (here: a copy with other weights at another address, same count) must not be served from it.  Such a launch
+    walks the list, so its buffers equal those of a state that never had an index, bit for bit."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import renderer as R
+    R.load()
+    scene = workloads.glowing_spheres_room()
+    w, h = 64, 64
+    r = R.Renderer(scene, w, h, 0)
+    r.render()
+    r.synchronize()
+    params = r.launch_params()
+    count = params.lightCount
+    assert count == 40960
+    lights = torch.from_numpy(R.device_to_host(params.lights, 92 * count).copy()).cuda()
+    table = lights.view(torch.float32).view(count, 23)
+    table[: count // 2, 16] *= 3.0                      # the weight (offset 64) of half the lights
+    other = R.LaunchParams.from_buffer_copy(params)
+    other.lights = lights.data_ptr()
+    total = np.float32(0.0)
+    for weight in table[:, 16].cpu().numpy():
+        total = np.float32(total + weight)
+    other.lightWeight = float(total)
+    other.sample = 0
+    index = engine.LightIndex(torch.from_numpy(R.device_to_host(params.lights, 92 * count).copy()).cuda())  # of the OLD weights
+    lib = engine.load()
+    images = []
+    for with_stale_index in (False, True):
+        state = C.c_void_p(0)
+        engine.check(lib.rt_wavefront_create(w * h, C.byref(state)))
+        try:
+            if with_stale_index:
+                engine.check(lib.rt_wavefront_set_light_index(state, C.c_void_p(index.memory.data_ptr()), count))
+            for k in range(7):  # the running mean of sample 0 is old + (new - old): start every run from zero
+                R.device_view(r.accumulation_buffer(k), w * h * 16).zero_()
+            torch.cuda.synchronize()
+            engine.check(lib.rt_render_sample(state, C.byref(other), 0, w * h, None))
+            torch.cuda.synchronize()
+            images.append(np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16).copy() for k in range(7)]))
+        finally:
+            lib.rt_wavefront_destroy(state)
+    differing = [int((images[0].view(np.uint32) != image.view(np.uint32)).sum()) for image in images]
+    assert differing == [0, 0], differing
+    assert images[0].view(np.float32).reshape(7, -1, 4)[0, :, :3].sum() > 0

@@ -384,9 +384,12 @@ def test_axis_parallel_rays_stay_cheap(engine, oracle):
     corners = scene["geometries"][0]["vertices"][:, :3]
     picks = rng.integers(0, len(corners), n)
     snap = rng.random(n) < 0.33
+    nudge = rng.integers(-1, 2, n)                 # ... or one float beside them, on either side
     for k in range(3):
         rows = snap & (d[:, k] == 0.0)
-        o[rows, k] = corners[picks[rows], k]
+        on = corners[picks[rows], k]
+        o[rows, k] = np.where(nudge[rows] < 0, np.nextafter(on, np.float32(-np.inf)),
+                              np.where(nudge[rows] > 0, np.nextafter(on, np.float32(np.inf)), on))
     assert (d[:, :3] == 0).any(axis=1).mean() > 0.9
     top, _ = check_scene(engine, oracle, scene, (o, d))
 
@@ -440,6 +443,19 @@ def test_geometry_records_must_cover_every_instance(engine):
     assert geometries >= 2
     records = (C.c_uint8 * (24 * geometries))()
     lib = engine.load()
+    engine.check(lib.rt_scene_set_geometry(top.handle, records, geometries))
     with pytest.raises(engine.EngineError, match="geometry beyond the records"):
         engine.check(lib.rt_scene_set_geometry(top.handle, records, geometries - 1))
-    engine.check(lib.rt_scene_set_geometry(top.handle, records, geometries))
+    # the refused call changed nothing: the scene still has the records of the call before it
+    import ctypes
+    params = (ctypes.c_uint8 * 344)()
+    ctypes.cast(params, ctypes.POINTER(ctypes.c_uint64))[168 // 8] = lib.rt_scene_handle(top.handle)
+    state = ctypes.c_void_p(0)
+    engine.check(lib.rt_wavefront_create(64, ctypes.byref(state)))
+    try:
+        with pytest.raises(engine.EngineError) as failure:   # the launch gets past the record check to the next one
+            engine.check(lib.rt_render_sample(state, params, 0, 1, None))
+        assert "rt_scene_set_geometry has not been called" not in str(failure.value)
+        assert "materials" in str(failure.value)
+    finally:
+        lib.rt_wavefront_destroy(state)
