@@ -413,6 +413,15 @@ rt_status rt_light_query(const rt_gpu_light* lights, uint32_t lightCount, float 
                          const float* uniform, const uint32_t* instance, const uint32_t* primitive, uint32_t n,
                          uint32_t* chosen, uint32_t* found, void* stream);
 
+/* The elementary functions of the shading kernels (include/rt_math.h: sequences of
+ * correctly rounded binary64 operations standing in for the sinf / cosf / powf /
+ * atan2f / acosf / exp2f calls of src/device.cu) evaluated on the device for n
+ * inputs: which = 0 sine(x), 1 cosine(x), 2 power(x, y), 3 arcTangent2(x, y) with x
+ * the ordinate, 4 arcCosine(x), 5 exp2(x).  All arrays device; y only for 2 and 3.
+ * A host build of the same header gives the same bits, which is what the tests
+ * use this entry for. */
+rt_status rt_shared_math(int which, const float* x, const float* y, uint32_t n, float* out, void* stream);
+
 /* Whether kernels put on these HIP streams (at most 16) really run side by
  * side: a process has a limited number of hardware queues, streams beyond
  * that number share one, and work on two streams of one queue runs in turn.

@@ -28,6 +28,7 @@ def load():
         "orc_photon_keys": (None, [_vp, _u32, _f32, _u32, _vp]),
         "orc_build_photon_grid": (None, [_vp, _u32, _f32, _u32, _vp, _vp]),
         "orc_photon_gather": (None, [_vp, _vp, _u32, _f32, _vp, _vp, _u32, _vp, C.c_int]),
+        "orc_shared_math": (None, [C.c_int, _vp, _vp, _u32, _vp]),
         "orc_seeded": (_u32, [_u32, _u32]),
         "orc_random": (_f32, [_vp]),
         "orc_scene_create": (_vp, []),
@@ -219,3 +220,15 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+SHARED_MATH = {"sine": 0, "cosine": 1, "power": 2, "arc_tangent2": 3, "arc_cosine": 4, "exp2": 5}
+
+
+def shared_math(name, x, y=None):
+    """include/rt_math.h compiled for the host: float32 arrays in, float32 array out."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else x, dtype=np.float32)
+    out = np.empty_like(x)
+    load().orc_shared_math(SHARED_MATH[name], _p(x), _p(y), x.size, _p(out))
+    return out

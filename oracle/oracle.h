@@ -31,6 +31,8 @@ extern "C" {
 void orc_photon_cell(const float* position3, float cellSize, int32_t* cell3);
 uint32_t orc_photon_bucket(const int32_t* cell3, uint32_t bucketCount);
 /* keys[i] = bucket(cell(positions[i])) for n packed float3 positions */
+// include/rt_math.h over arrays: which = 0 sine, 1 cosine, 2 power(x, y), 3 arcTangent2(x, y), 4 arcCosine, 5 exp2.
+void orc_shared_math(int which, const float* x, const float* y, uint32_t n, float* out);
 void orc_photon_keys(const float* positions, uint32_t n, float cellSize, uint32_t bucketCount, uint32_t* keys);
 
 /* ---- photon grid (photon_grid.cu:17-83) --------------------------------

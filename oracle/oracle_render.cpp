@@ -9,6 +9,8 @@
 #include "oracle.h"
 #include "oracle_internal.h"
 
+#include "rt_math.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -16,6 +18,24 @@
 #include <vector>
 
 namespace {
+
+// The elementary functions come from rt_math.h (sequences of correctly rounded binary64 operations, the same
+// bits on every IEEE machine), which the device code uses as well; -DRT_LIBM_MATH takes the host libm's.
+#ifdef RT_LIBM_MATH
+float mathSin(float x) { return std::sin(x); }
+float mathCos(float x) { return std::cos(x); }
+float mathPow(float x, float y) { return std::pow(x, y); }
+float mathAtan2(float y, float x) { return std::atan2(y, x); }
+float mathAcos(float x) { return std::acos(x); }
+float mathExp2(float x) { return std::exp2(x); }
+#else
+float mathSin(float x) { return rtm::sine(x); }
+float mathCos(float x) { return rtm::cosine(x); }
+float mathPow(float x, float y) { return rtm::power(x, y); }
+float mathAtan2(float y, float x) { return rtm::arcTangent2(y, x); }
+float mathAcos(float x) { return rtm::arcCosine(x); }
+float mathExp2(float x) { return rtm::exp2(x); }
+#endif
 
 struct F3 {
     float x, y, z;
@@ -51,7 +71,7 @@ float rnd(uint32_t& state) { return orc_random(&state); }
 
 // device.cu:81-84
 float linear(float value) {
-    return value <= 0.04045f ? value / 12.92f : std::pow((value + 0.055f) / 1.055f, 2.4f);
+    return value <= 0.04045f ? value / 12.92f : mathPow((value + 0.055f) / 1.055f, 2.4f);
 }
 
 // device.cu:86-98
@@ -84,8 +104,8 @@ F4 texture(const Ctx& c, const rt_gpu_texture_ref& reference, const rt_hit& hit,
     const rt_gpu_texture source = c.p->textures[reference.texture];
     const rt_float2 input = reference.texCoord == 1U ? hit.uv1 : hit.uv;
     const float sx = input.x * reference.scale.x, sy = input.y * reference.scale.y;
-    const float cosine = std::cos(reference.rotation);
-    const float sine = std::sin(reference.rotation);
+    const float cosine = mathCos(reference.rotation);
+    const float sine = mathSin(reference.rotation);
     const float u = reference.offset.x + cosine * sx - sine * sy;
     const float v = reference.offset.y + sine * sx + cosine * sy;
     const float x = u * source.width - 0.5f;
@@ -161,9 +181,9 @@ F3 sky(F3) { return {0.1f, 0.1f, 0.1f}; }  // device.cu:235-237
 
 // device.cu:239-245
 void environmentUv(const Ctx& c, F3 direction, float& u, float& v) {
-    u = std::atan2(direction.z, direction.x) * 0.15915494f + 0.5f + c.p->environmentRotation * 0.15915494f;
+    u = mathAtan2(direction.z, direction.x) * 0.15915494f + 0.5f + c.p->environmentRotation * 0.15915494f;
     u -= std::floor(u);
-    v = std::acos(std::fmin(std::fmax(direction.y, -1.0f), 1.0f)) * 0.31830989f;
+    v = mathAcos(std::fmin(std::fmax(direction.y, -1.0f), 1.0f)) * 0.31830989f;
 }
 
 // device.cu:247-253
@@ -203,7 +223,7 @@ F3 cosineDirection(F3 normal, uint32_t& rng) {
     const float z = std::sqrt(std::fmax(0.0f, 1.0f - radius * radius));
     const F3 tangent = basisTangent(normal);
     const F3 bitangent = cross(normal, tangent);
-    return normalize(tangent * (radius * std::cos(phi)) + bitangent * (radius * std::sin(phi)) + normal * z);
+    return normalize(tangent * (radius * mathCos(phi)) + bitangent * (radius * mathSin(phi)) + normal * z);
 }
 
 float roughnessAlpha(float roughness) { return std::fmax(roughness * roughness, 1e-4f); }  // device.cu:286-288
@@ -220,8 +240,8 @@ F3 ggxNormal(F3 view, F3 normal, float alpha, uint32_t& rng) {
     const F3 basisY = cross(stretched, basisX);
     const float radius = std::sqrt(rnd(rng));
     const float phi = 6.2831853f * rnd(rng);
-    const float x = radius * std::cos(phi);
-    float y = radius * std::sin(phi);
+    const float x = radius * mathCos(phi);
+    float y = radius * mathSin(phi);
     const float lerp = 0.5f * (1.0f + stretched.z);
     y = (1.0f - lerp) * std::sqrt(std::fmax(0.0f, 1.0f - x * x)) + lerp * y;
     const F3 hemisphere = basisX * x + basisY * y + stretched * std::sqrt(std::fmax(0.0f, 1.0f - x * x - y * y));
@@ -246,12 +266,12 @@ float maskingRatio(float viewCosine, float lightCosine, float alpha) {
 float fresnel(float cosine, float ior) {
     const float r = (1.0f - ior) / (1.0f + ior);
     const float r2 = r * r;
-    return r2 + (1.0f - r2) * std::pow(std::fmax(1.0f - cosine, 0.0f), 5.0f);
+    return r2 + (1.0f - r2) * mathPow(std::fmax(1.0f - cosine, 0.0f), 5.0f);
 }
 
 // device.cu:345-350
 F3 schlick(F3 f0, float cosine) {
-    const float scale = std::pow(std::fmax(1.0f - cosine, 0.0f), 5.0f);
+    const float scale = mathPow(std::fmax(1.0f - cosine, 0.0f), 5.0f);
     return {f0.x + (1.0f - f0.x) * scale, f0.y + (1.0f - f0.y) * scale, f0.z + (1.0f - f0.z) * scale};
 }
 
@@ -267,25 +287,25 @@ F3 absorption(const rt_gpu_material& m, float distance) {
     if (!std::isfinite(m.attenuationDistance) || m.attenuationDistance <= 0.0f)
         return {1.0f, 1.0f, 1.0f};
     const float scale = distance / m.attenuationDistance;
-    return {std::pow(std::fmax(m.attenuationColor.x, 1e-4f), scale),
-            std::pow(std::fmax(m.attenuationColor.y, 1e-4f), scale),
-            std::pow(std::fmax(m.attenuationColor.z, 1e-4f), scale)};
+    return {mathPow(std::fmax(m.attenuationColor.x, 1e-4f), scale),
+            mathPow(std::fmax(m.attenuationColor.y, 1e-4f), scale),
+            mathPow(std::fmax(m.attenuationColor.z, 1e-4f), scale)};
 }
 
 // device.cu:372-377
 F3 lensSample(const Ctx& c, uint32_t& rng) {
     const float radius = std::sqrt(rnd(rng));
     const float angle = 6.2831853f * rnd(rng);
-    return f3(c.p->lensU) * (radius * std::cos(angle) * c.p->aperture) +
-           f3(c.p->lensV) * (radius * std::sin(angle) * c.p->aperture);
+    return f3(c.p->lensU) * (radius * mathCos(angle) * c.p->aperture) +
+           f3(c.p->lensV) * (radius * mathSin(angle) * c.p->aperture);
 }
 
 // device.cu:379-386
 F3 aces(F3 color) {
     color = color * (2.51f * color + 0.03f) / (color * (2.43f * color + 0.59f) + 0.14f);
-    return {std::pow(std::fmin(std::fmax(color.x, 0.0f), 1.0f), 1.0f / 2.2f),
-            std::pow(std::fmin(std::fmax(color.y, 0.0f), 1.0f), 1.0f / 2.2f),
-            std::pow(std::fmin(std::fmax(color.z, 0.0f), 1.0f), 1.0f / 2.2f)};
+    return {mathPow(std::fmin(std::fmax(color.x, 0.0f), 1.0f), 1.0f / 2.2f),
+            mathPow(std::fmin(std::fmax(color.y, 0.0f), 1.0f), 1.0f / 2.2f),
+            mathPow(std::fmin(std::fmax(color.z, 0.0f), 1.0f), 1.0f / 2.2f)};
 }
 
 // device.cu:388-397
@@ -361,8 +381,8 @@ EnvironmentSample sampleEnvironment(const Ctx& c, uint32_t& rng) {
     const float v = (static_cast<float>(index / c.p->environmentWidth) + rnd(rng)) / c.p->environmentHeight;
     const float theta = 3.14159265f * v;
     const float phi = 6.2831853f * (u - 0.5f) - c.p->environmentRotation;
-    const float sine = std::sin(theta);
-    const F3 direction{std::cos(phi) * sine, std::cos(theta), std::sin(phi) * sine};
+    const float sine = mathSin(theta);
+    const F3 direction{mathCos(phi) * sine, mathCos(theta), mathSin(phi) * sine};
     const float solidAngle = 19.7392088f * std::fmax(sine, 1e-6f) / static_cast<float>(count);
     return {direction, environment(c, direction), probability / solidAngle};
 }
@@ -419,8 +439,8 @@ LightSample sampleLight(const Ctx& c, F3 position, uint32_t& rng) {
         sample.radiance /= distanceSquared;
         if (selected->type == 1U) {
             const float cone = dot(f3(selected->b), -sample.direction);
-            const float outer = std::cos(selected->outerCone);
-            const float inner = std::cos(selected->innerCone);
+            const float outer = mathCos(selected->outerCone);
+            const float inner = mathCos(selected->innerCone);
             const float falloff = saturate((cone - outer) / std::fmax(inner - outer, 1e-5f));
             sample.radiance = sample.radiance * (falloff * falloff);
             if (falloff <= 0.0f)
@@ -453,7 +473,7 @@ float environmentPdf(const Ctx& c, F3 direction) {
     const unsigned index = y * c.p->environmentWidth + x;
     const float probability = c.p->environmentCdf[index] - (index ? c.p->environmentCdf[index - 1U] : 0.0f);
     const float theta = 3.14159265f * (static_cast<float>(y) + 0.5f) / c.p->environmentHeight;
-    const float solidAngle = 19.7392088f * std::fmax(std::sin(theta), 1e-6f) /
+    const float solidAngle = 19.7392088f * std::fmax(mathSin(theta), 1e-6f) /
                              static_cast<float>(c.p->environmentWidth * c.p->environmentHeight);
     return c.p->environmentWeight / c.p->lightWeight * probability / solidAngle;
 }
@@ -503,8 +523,8 @@ F3 directionAround(F3 axis, float cosine, uint32_t& rng) {
     const float sine = std::sqrt(std::fmax(0.0f, 1.0f - cosine * cosine));
     const float angle = 6.2831853f * rnd(rng);
     const F3 tangent = basisTangent(axis);
-    return normalize(axis * cosine + tangent * (sine * std::cos(angle)) +
-                     cross(axis, tangent) * (sine * std::sin(angle)));
+    return normalize(axis * cosine + tangent * (sine * mathCos(angle)) +
+                     cross(axis, tangent) * (sine * mathSin(angle)));
 }
 
 // device.cu:641-650
@@ -512,7 +532,7 @@ F3 diskOffset(F3 normal, float radius, uint32_t& rng) {
     const float distance = std::sqrt(rnd(rng)) * radius;
     const float angle = 6.2831853f * rnd(rng);
     const F3 tangent = basisTangent(normal);
-    return tangent * (distance * std::cos(angle)) + cross(normal, tangent) * (distance * std::sin(angle));
+    return tangent * (distance * mathCos(angle)) + cross(normal, tangent) * (distance * mathSin(angle));
 }
 
 // device.cu:652-712
@@ -546,10 +566,10 @@ PhotonEmission emitPhoton(const Ctx& c, uint32_t& rng) {
     } else {
         photon.origin = f3(light->a);
         if (light->type == 1U) {
-            const float outer = std::cos(light->outerCone);
+            const float outer = mathCos(light->outerCone);
             const float cosine = 1.0f - rnd(rng) * (1.0f - outer);
             photon.direction = directionAround(normalize(f3(light->b)), cosine, rng);
-            const float inner = std::cos(light->innerCone);
+            const float inner = mathCos(light->innerCone);
             const float falloff = saturate((cosine - outer) / std::fmax(inner - outer, 1e-5f));
             photon.power = f3(light->emission) * (6.2831853f * (1.0f - outer) * falloff * falloff * normalization);
         } else {
@@ -780,7 +800,7 @@ void renderPixel(const Ctx& c, uint32_t px, uint32_t py) {
     blend(p.albedoGuide, guideAlbedo, weight);
     blend(p.normalGuide, guideNormal, weight);
     if (p.output) {
-        const F3 mapped = aces(accumulated * std::exp2(p.exposure));
+        const F3 mapped = aces(accumulated * mathExp2(p.exposure));
         p.output[index] = rt_uchar4{static_cast<unsigned char>(mapped.x * 255.0f + 0.5f),
                                     static_cast<unsigned char>(mapped.y * 255.0f + 0.5f),
                                     static_cast<unsigned char>(mapped.z * 255.0f + 0.5f), 255};
@@ -899,3 +919,18 @@ void orc_light_walks(const rt_gpu_light* lights, uint32_t lightCount, float ligh
 }
 
 }  // extern "C"
+
+// The shared elementary functions over arrays, for the tests that pin them: which = 0 sine, 1 cosine,
+// 2 power(x, y), 3 arcTangent2(x = ordinate, y = abscissa), 4 arcCosine, 5 exp2.
+extern "C" void orc_shared_math(int which, const float* x, const float* y, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        switch (which) {
+        case 0: out[i] = rtm::sine(x[i]); break;
+        case 1: out[i] = rtm::cosine(x[i]); break;
+        case 2: out[i] = rtm::power(x[i], y[i]); break;
+        case 3: out[i] = rtm::arcTangent2(x[i], y[i]); break;
+        case 4: out[i] = rtm::arcCosine(x[i]); break;
+        default: out[i] = rtm::exp2(x[i]); break;
+        }
+    }
+}

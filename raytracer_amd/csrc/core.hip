@@ -1,5 +1,6 @@
 // Error reporting shared by every entry point of the engine library.
 #include "common.h"
+#include "rt_math.h"
 
 namespace rt {
 namespace {
@@ -21,11 +22,39 @@ __global__ void occupyKernel(unsigned long long ticks, unsigned int* sink) {
     if (sink && spins == 0xffffffffU)
         *sink = spins;
 }
+
+// The elementary functions the shading kernels use (rt_math.h), over arrays.
+__global__ __launch_bounds__(256) void sharedMathKernel(int which, const float* x, const float* y, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    switch (which) {
+    case 0: out[i] = rtm::sine(x[i]); break;
+    case 1: out[i] = rtm::cosine(x[i]); break;
+    case 2: out[i] = rtm::power(x[i], y[i]); break;
+    case 3: out[i] = rtm::arcTangent2(x[i], y[i]); break;
+    case 4: out[i] = rtm::arcCosine(x[i]); break;
+    default: out[i] = rtm::exp2(x[i]); break;
+    }
+}
 }  // namespace
 
 }  // namespace rt
 
 extern "C" {
+
+rt_status rt_shared_math(int which, const float* x, const float* y, uint32_t n, float* out, void* stream) {
+    if (which < 0 || which > 5)
+        return rt::failInvalid("which: 0 sine .. 5 exp2");
+    if (n == 0)
+        return RT_SUCCESS;
+    if (!x || !out || ((which == 2 || which == 3) && !y))
+        return rt::failInvalid("null pointer");
+    hipLaunchKernelGGL(rt::sharedMathKernel, dim3(rt::divUp(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), which, x,
+                       y, n, out);
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
 
 rt_status rt_streams_run_concurrently(void* const* streams, uint32_t count, int* concurrent) {
     if (!streams || !concurrent || count == 0 || count > 16)

@@ -7,8 +7,29 @@
 
 #include "bvh.h"
 #include "light_index.h"
+#include "rt_math.h"
 
 namespace rt {
+
+// Sine, cosine, power, arc functions and 2^x come from rt_math.h, sequences of correctly rounded binary64
+// operations that give the same bits on the host, where the CPU restatement of this code uses them too:
+// a device math library and a host libm differ in the last place of these functions, and one such bit sends
+// a path another way.  -DRT_LIBM_MATH takes the device library's functions instead, for comparison.
+#ifdef RT_LIBM_MATH
+__device__ inline float mathSin(float x) { return sinf(x); }
+__device__ inline float mathCos(float x) { return cosf(x); }
+__device__ inline float mathPow(float x, float y) { return powf(x, y); }
+__device__ inline float mathAtan2(float y, float x) { return atan2f(y, x); }
+__device__ inline float mathAcos(float x) { return acosf(x); }
+__device__ inline float mathExp2(float x) { return exp2f(x); }
+#else
+__device__ inline float mathSin(float x) { return rtm::sine(x); }
+__device__ inline float mathCos(float x) { return rtm::cosine(x); }
+__device__ inline float mathPow(float x, float y) { return rtm::power(x, y); }
+__device__ inline float mathAtan2(float y, float x) { return rtm::arcTangent2(y, x); }
+__device__ inline float mathAcos(float x) { return rtm::arcCosine(x); }
+__device__ inline float mathExp2(float x) { return rtm::exp2(x); }
+#endif
 
 struct V3 {
     float x, y, z;
@@ -54,7 +75,7 @@ __device__ inline float random01(uint32_t& state) {
 
 // device.cu:81-84
 __device__ inline float srgbToLinear(float value) {
-    return value <= 0.04045f ? value / 12.92f : powf((value + 0.055f) / 1.055f, 2.4f);
+    return value <= 0.04045f ? value / 12.92f : mathPow((value + 0.055f) / 1.055f, 2.4f);
 }
 
 // value mod n for n > 0 as ((value % n) + n) % n gives it, with one division instead of two, and none for a
@@ -112,8 +133,8 @@ __device__ inline float4 sampleTexture(const rt_gpu_texture* textures, const rt_
     const float sx = input.x * reference.scale.x, sy = input.y * reference.scale.y;
     // a rotation of zero (either sign) has the cosine 1 and itself as its sine, exactly
     const bool unrotated = reference.rotation == 0.0f;
-    const float cosine = unrotated ? 1.0f : cosf(reference.rotation);
-    const float sine = unrotated ? reference.rotation : sinf(reference.rotation);
+    const float cosine = unrotated ? 1.0f : mathCos(reference.rotation);
+    const float sine = unrotated ? reference.rotation : mathSin(reference.rotation);
     const float u = reference.offset.x + cosine * sx - sine * sy;
     const float v = reference.offset.y + sine * sx + cosine * sy;
     const float x = u * source.width - 0.5f;
@@ -192,9 +213,9 @@ __device__ inline bool refractThrough(V3 direction, V3 normal, float eta, V3& re
 
 // device.cu:239-271: latitude/longitude environment lookup, constant grey when absent
 __device__ inline void environmentCoordinates(const rt_launch_params& p, V3 direction, float& u, float& v) {
-    u = atan2f(direction.z, direction.x) * 0.15915494f + 0.5f + p.environmentRotation * 0.15915494f;
+    u = mathAtan2(direction.z, direction.x) * 0.15915494f + 0.5f + p.environmentRotation * 0.15915494f;
     u -= floorf(u);
-    v = acosf(fminf(fmaxf(direction.y, -1.0f), 1.0f)) * 0.31830989f;
+    v = mathAcos(fminf(fmaxf(direction.y, -1.0f), 1.0f)) * 0.31830989f;
 }
 
 __device__ inline V3 environmentPixel(const rt_launch_params& p, int x, int y) {
@@ -232,7 +253,7 @@ __device__ inline V3 sampleCosine(V3 normal, uint32_t& rng) {
     const float z = sqrtf(fmaxf(0.0f, 1.0f - radius * radius));
     const V3 tangent = frameTangent(normal);
     const V3 bitangent = cross(normal, tangent);
-    return normalize(tangent * (radius * cosf(phi)) + bitangent * (radius * sinf(phi)) + normal * z);
+    return normalize(tangent * (radius * mathCos(phi)) + bitangent * (radius * mathSin(phi)) + normal * z);
 }
 
 __device__ inline float alphaOf(float roughness) { return fmaxf(roughness * roughness, 1e-4f); }  // :286-288
@@ -249,8 +270,8 @@ __device__ inline V3 sampleVisibleNormal(V3 view, V3 normal, float alpha, uint32
     const V3 basisY = cross(stretched, basisX);
     const float radius = sqrtf(random01(rng));
     const float phi = 6.2831853f * random01(rng);
-    const float x = radius * cosf(phi);
-    float y = radius * sinf(phi);
+    const float x = radius * mathCos(phi);
+    float y = radius * mathSin(phi);
     const float lerp = 0.5f * (1.0f + stretched.z);
     y = (1.0f - lerp) * sqrtf(fmaxf(0.0f, 1.0f - x * x)) + lerp * y;
     const V3 hemisphere = basisX * x + basisY * y + stretched * sqrtf(fmaxf(0.0f, 1.0f - x * x - y * y));
@@ -274,11 +295,11 @@ __device__ inline float maskingRatio(float viewCosine, float lightCosine, float 
 __device__ inline float dielectricFresnel(float cosine, float ior) {
     const float r = (1.0f - ior) / (1.0f + ior);
     const float r2 = r * r;
-    return r2 + (1.0f - r2) * powf(fmaxf(1.0f - cosine, 0.0f), 5.0f);
+    return r2 + (1.0f - r2) * mathPow(fmaxf(1.0f - cosine, 0.0f), 5.0f);
 }
 
 __device__ inline V3 schlickFresnel(V3 f0, float cosine) {
-    const float scale = powf(fmaxf(1.0f - cosine, 0.0f), 5.0f);
+    const float scale = mathPow(fmaxf(1.0f - cosine, 0.0f), 5.0f);
     return {f0.x + (1.0f - f0.x) * scale, f0.y + (1.0f - f0.y) * scale, f0.z + (1.0f - f0.z) * scale};
 }
 
@@ -293,15 +314,15 @@ __device__ inline V3 mediumAbsorption(const rt_gpu_material& m, float distance) 
     if (!isfinite(m.attenuationDistance) || m.attenuationDistance <= 0.0f)
         return {1.0f, 1.0f, 1.0f};
     const float scale = distance / m.attenuationDistance;
-    return {powf(fmaxf(m.attenuationColor.x, 1e-4f), scale), powf(fmaxf(m.attenuationColor.y, 1e-4f), scale),
-            powf(fmaxf(m.attenuationColor.z, 1e-4f), scale)};
+    return {mathPow(fmaxf(m.attenuationColor.x, 1e-4f), scale), mathPow(fmaxf(m.attenuationColor.y, 1e-4f), scale),
+            mathPow(fmaxf(m.attenuationColor.z, 1e-4f), scale)};
 }
 
 // device.cu:379-386
 __device__ inline V3 acesTonemap(V3 color) {
     color = color * (2.51f * color + 0.03f) / (color * (2.43f * color + 0.59f) + 0.14f);
-    return {powf(fminf(fmaxf(color.x, 0.0f), 1.0f), 1.0f / 2.2f), powf(fminf(fmaxf(color.y, 0.0f), 1.0f), 1.0f / 2.2f),
-            powf(fminf(fmaxf(color.z, 0.0f), 1.0f), 1.0f / 2.2f)};
+    return {mathPow(fminf(fmaxf(color.x, 0.0f), 1.0f), 1.0f / 2.2f), mathPow(fminf(fmaxf(color.y, 0.0f), 1.0f), 1.0f / 2.2f),
+            mathPow(fminf(fmaxf(color.z, 0.0f), 1.0f), 1.0f / 2.2f)};
 }
 
 // device.cu:399-413
@@ -364,8 +385,8 @@ __device__ inline EnvironmentDraw drawEnvironment(const rt_launch_params& p, uin
     const float v = (static_cast<float>(index / p.environmentWidth) + random01(rng)) / p.environmentHeight;
     const float theta = 3.14159265f * v;
     const float phi = 6.2831853f * (u - 0.5f) - p.environmentRotation;
-    const float sine = sinf(theta);
-    const V3 direction{cosf(phi) * sine, cosf(theta), sinf(phi) * sine};
+    const float sine = mathSin(theta);
+    const V3 direction{mathCos(phi) * sine, mathCos(theta), mathSin(phi) * sine};
     const float solidAngle = 19.7392088f * fmaxf(sine, 1e-6f) / static_cast<float>(count);
     return {direction, environmentRadiance(p, direction), probability / solidAngle};
 }
@@ -435,8 +456,8 @@ __device__ inline LightDraw drawLight(const rt_launch_params& p, const LightInde
         sample.radiance = sample.radiance / distanceSquared;
         if (light.type == 1U) {
             const float cone = dot(v3(light.b), -sample.direction);
-            const float outer = cosf(light.outerCone);
-            const float inner = cosf(light.innerCone);
+            const float outer = mathCos(light.outerCone);
+            const float inner = mathCos(light.innerCone);
             const float falloff = saturate((cone - outer) / fmaxf(inner - outer, 1e-5f));
             sample.radiance = sample.radiance * (falloff * falloff);
             if (falloff <= 0.0f)
@@ -459,7 +480,7 @@ __device__ inline float environmentDensity(const rt_launch_params& p, V3 directi
     const float probability = p.environmentCdf[index] - (index ? p.environmentCdf[index - 1U] : 0.0f);
     const float theta = 3.14159265f * (static_cast<float>(y) + 0.5f) / p.environmentHeight;
     const float solidAngle =
-        19.7392088f * fmaxf(sinf(theta), 1e-6f) / static_cast<float>(p.environmentWidth * p.environmentHeight);
+        19.7392088f * fmaxf(mathSin(theta), 1e-6f) / static_cast<float>(p.environmentWidth * p.environmentHeight);
     return p.environmentWeight / p.lightWeight * probability / solidAngle;
 }
 
@@ -492,14 +513,14 @@ __device__ inline V3 sampleAround(V3 axis, float cosine, uint32_t& rng) {
     const float sine = sqrtf(fmaxf(0.0f, 1.0f - cosine * cosine));
     const float angle = 6.2831853f * random01(rng);
     const V3 tangent = frameTangent(axis);
-    return normalize(axis * cosine + tangent * (sine * cosf(angle)) + cross(axis, tangent) * (sine * sinf(angle)));
+    return normalize(axis * cosine + tangent * (sine * mathCos(angle)) + cross(axis, tangent) * (sine * mathSin(angle)));
 }
 
 __device__ inline V3 sampleDisk(V3 normal, float radius, uint32_t& rng) {
     const float distance = sqrtf(random01(rng)) * radius;
     const float angle = 6.2831853f * random01(rng);
     const V3 tangent = frameTangent(normal);
-    return tangent * (distance * cosf(angle)) + cross(normal, tangent) * (distance * sinf(angle));
+    return tangent * (distance * mathCos(angle)) + cross(normal, tangent) * (distance * mathSin(angle));
 }
 
 // The rough-dielectric event shared by the camera path (device.cu:954-997) and

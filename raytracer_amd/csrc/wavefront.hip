@@ -208,8 +208,8 @@ __global__ __launch_bounds__(kShadeBlock) void generateKernel(rt_launch_params p
     // lensSample, device.cu:372-377 (drawn even with a closed aperture)
     const float radius = sqrtf(random01(rng));
     const float angle = 6.2831853f * random01(rng);
-    const V3 origin = v3(p.eye) + (v3(p.lensU) * (radius * cosf(angle) * p.aperture) +
-                                   v3(p.lensV) * (radius * sinf(angle) * p.aperture));
+    const V3 origin = v3(p.eye) + (v3(p.lensU) * (radius * mathCos(angle) * p.aperture) +
+                                   v3(p.lensV) * (radius * mathSin(angle) * p.aperture));
     const V3 direction = normalize(focalPoint - origin);
     b.rayOrigin[0][i] = make_float4(origin.x, origin.y, origin.z, 0.001f);
     b.rayDirection[0][i] = make_float4(direction.x, direction.y, direction.z, 1e16f);
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
     }
     const V3 accumulated = mean[0];
     if (p.output) {
-        const V3 mapped = acesTonemap(accumulated * exp2f(p.exposure));
+        const V3 mapped = acesTonemap(accumulated * mathExp2(p.exposure));
         rt_uchar4 out;
         out.x = static_cast<unsigned char>(mapped.x * 255.0f + 0.5f);
         out.y = static_cast<unsigned char>(mapped.y * 255.0f + 0.5f);
@@ -790,10 +790,10 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
             } else {
                 origin = v3(light.a);
                 if (light.type == 1U) {
-                    const float outer = cosf(light.outerCone);
+                    const float outer = mathCos(light.outerCone);
                     const float cosine = 1.0f - random01(rng) * (1.0f - outer);
                     direction = sampleAround(normalize(v3(light.b)), cosine, rng);
-                    const float inner = cosf(light.innerCone);
+                    const float inner = mathCos(light.innerCone);
                     const float falloff = saturate((cosine - outer) / fmaxf(inner - outer, 1e-5f));
                     power = v3(light.emission) * (6.2831853f * (1.0f - outer) * falloff * falloff * normalization);
                 } else {

@@ -87,6 +87,7 @@ SYMBOLS = {
     "rt_light_query": (C.c_int, [_vp, _u32, C.c_float, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rt_wavefront_set_accumulate_events": (C.c_int, [_vp, _vp, _vp]),
     "rt_wavefront_set_sample_batch": (C.c_int, [_vp, _u32, _u32]),
+    "rt_shared_math": (C.c_int, [C.c_int, _vp, _vp, _u32, _vp, _vp]),
     "rt_streams_run_concurrently": (C.c_int, [_vp, _u32, _vp]),
     "rt_wavefront_timings": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_u32), _vp]),
 }
@@ -410,3 +411,15 @@ def light_query(lights, light_weight, index=None, uniform=None, instance=None, p
                                 _ptr(chosen) if chosen is not None else None,
                                 _ptr(found) if found is not None else None, _stream(stream)))
     return chosen, found
+
+
+SHARED_MATH = {"sine": 0, "cosine": 1, "power": 2, "arc_tangent2": 3, "arc_cosine": 4, "exp2": 5}
+
+
+def shared_math(name, x, y=None, stream=None):
+    """include/rt_math.h on the device: x (and y for power / arc_tangent2) float32 device tensors -> float32."""
+    import torch
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    check(load().rt_shared_math(SHARED_MATH[name], _ptr(x), _ptr(y), x.numel(), _ptr(out), _stream(stream)))
+    return out

@@ -1,0 +1,144 @@
+"""The engine's images and photon lists against the CPU oracle's, bit for bit.
+
+The shading code takes its sines, cosines, powers, arc functions and 2^x from include/rt_math.h, fixed sequences
+of correctly rounded operations that give the same bits on the GPU and on the host; every other operation of the
+integrator is an IEEE addition, multiplication, division or square root evaluated in the same order on both sides
+(-ffp-contract=off).  So nothing is left to round differently, and the renderer's seven accumulation buffers must
+EQUAL the oracle's - not to a tolerance: a pixel that differs is a difference in the algorithm (a branch, a draw
+order, an operation order), not noise.  The oracle is fed the renderer's own device tables (HostParams), so the
+host-side set-up arithmetic (tan of the field of view, environment rows) does not enter.
+
+These are the tests the looser bounds of test_gpu_render.py / test_gpu_configs.py stand behind: those still hold
+for a build with -DRT_LIBM_MATH, where paths fork on last-place differences of the math libraries."""
+import numpy as np
+import pytest
+
+from raytracer_amd import workloads
+from helpers import HostParams, oracle_scene
+
+pytestmark = pytest.mark.gpu
+
+@pytest.fixture(scope="module")
+def R(engine):
+    from raytracer_amd import renderer
+    renderer.load()
+    return renderer
+
+
+NAMES = ("accumulation", "diffuse", "reflection", "refraction", "caustics", "albedo guide", "normal guide")
+
+
+def buffers_of(R, r, pixels):
+    return [R.device_to_host(r.accumulation_buffer(k), pixels * 16).view(np.float32).reshape(-1, 4).copy() for k in range(7)]
+
+
+def assert_identical(gpu, cpu, what):
+    report = []
+    for k in range(7):
+        differing = np.nonzero((gpu[k].view(np.uint32) != cpu[k].view(np.uint32)).any(axis=1))[0]
+        if len(differing):
+            report.append(f"{NAMES[k]}: {len(differing)} pixels, first {differing[:8].tolist()}, "
+                          f"gpu {gpu[k][differing[0]].tolist()} cpu {cpu[k][differing[0]].tolist()}")
+    assert not report, what + ": " + "; ".join(report)
+
+
+def render_both(R, oracle, scene, w, h, samples, profile=0, budget=None, threads=16):
+    r = R.Renderer(scene, w, h, profile)
+    if budget:
+        r.set_photon_budget(*budget)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    radius = r.caustic_radius()
+    photons = []
+    for s in range(samples):
+        r.render()
+        if profile and s % 4 == 0:  # renderer.cpp:780: a photon pass before samples 0, 4, 8, ...
+            host.params.photonRadius = radius
+            host.params.photonPass = s // 4
+            ph, wanted = ref.trace_photons(host.params, 0, budget[0], budget[1], threads=threads)
+            offsets, srt = oracle.build_photon_grid(ph, radius, budget[2])
+            host.sorted[: len(srt)] = srt
+            host.cell_start[:] = offsets
+            photons.append(ph)
+        host.params.sample = s
+        ref.render_sample(host.params, 0, w * h, threads)
+    r.synchronize()
+    return r, host, photons
+
+
+def test_cornell_box(R, oracle):
+    """Point light and emissive panel (light sampling with the power heuristic, shadow rays, Russian roulette
+    from the fourth bounce), four samples at 256 x 256."""
+    for light in ("point", "panel"):
+        scene = workloads.cornell_box(light=light)
+        w = h = 256
+        r, host, _ = render_both(R, oracle, scene, w, h, 4)
+        assert host.aov[0][:, :3].mean() > 0.01
+        assert_identical(buffers_of(R, r, w * h), host.aov, f"cornell box, {light} light")
+
+
+def test_dragon_cornell(R, oracle):
+    """871 k triangles of absorbing glass: refraction, total internal reflection, Beer-Lambert absorption
+    (powers with fractional exponents), area light."""
+    scene = workloads.dragon_cornell()
+    w, h = 240, 135
+    r, host, _ = render_both(R, oracle, scene, w, h, 2)
+    assert host.aov[3][:, :3].sum() > 0
+    assert_identical(buffers_of(R, r, w * h), host.aov, "dragon-cornell stand-in")
+
+
+def test_sphere_field(R, oracle):
+    """Environment map with importance sampling (arc tangent and arc cosine per lookup, sine per density),
+    directional light, thin lens, 504 instances, rough metal and clear glass."""
+    scene = workloads.sphere_field(sky=True)
+    w, h = 256, 144
+    r, host, _ = render_both(R, oracle, scene, w, h, 2)
+    assert host.aov[0][:, :3].mean() > 0.05
+    assert_identical(buffers_of(R, r, w * h), host.aov, "sphere field")
+
+
+def test_caustic_lab_with_its_photon_maps(R, oracle):
+    """Final profile, 32 bounces, spot light (cosines of the cone), gold ring and glass tumbler: the photon list of
+    both passes photon by photon, and six samples gathering from them."""
+    scene = workloads.caustic_lab()
+    w, h = 96, 54
+    budget = (1 << 18, 1 << 17, 1 << 15)
+    r = R.Renderer(scene, w, h, 1)
+    r.set_photon_budget(*budget)
+    r.set_manual_photon_passes(True)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    radius = r.caustic_radius()
+    for s in range(6):
+        if s % 4 == 0:
+            assert r.photon_pass_due()
+            r.begin_photon_pass()
+            stored = r.trace_photon_range(0, budget[0])
+            gpu_photons = R.device_to_host(r.photon_buffer(), stored * 36).view(np.float32).reshape(-1, 9).copy()
+            r.finish_photon_pass(stored)
+            host.params.photonRadius = radius
+            host.params.photonPass = s // 4
+            ph, wanted = ref.trace_photons(host.params, 0, budget[0], budget[1], threads=16)
+            assert wanted == stored and stored > 1000
+            assert np.array_equal(gpu_photons.view(np.uint32), ph.view(np.uint32)), f"photon list of pass {s // 4}"
+            offsets, srt = oracle.build_photon_grid(ph, radius, budget[2])
+            host.sorted[: len(srt)] = srt
+            host.cell_start[:] = offsets
+        r.render()
+        host.params.sample = s
+        ref.render_sample(host.params, 0, w * h, 16)
+    r.synchronize()
+    assert host.aov[4][:, :3].sum() > 0
+    assert_identical(buffers_of(R, r, w * h), host.aov, "caustic-lab, final profile")
+
+
+@pytest.mark.parametrize("which", ["sky", "maps"])
+def test_textured_scenes(R, oracle, which):
+    """Texture lookups with transforms (a rotation: sine and cosine), sRGB decoding (power 2.4), the environment
+    with a lens, glass and metal; and every material map (base colour, metallic-roughness, normal, emissive,
+    transmission, thickness)."""
+    scene = workloads.textured_sky_scene() if which == "sky" else workloads.material_map_scene()
+    w, h = 160, 90
+    r, host, _ = render_both(R, oracle, scene, w, h, 2)
+    assert host.aov[0][:, :3].mean() > 0.0
+    assert_identical(buffers_of(R, r, w * h), host.aov, f"textured scene ({which})")
