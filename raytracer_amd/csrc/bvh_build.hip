@@ -1007,7 +1007,7 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
 }
 
 rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
-                    hipStream_t stream, rt_blas* blas) {
+                    hipStream_t stream, rt_blas* blas, bool allowRefine = true) {
     hipEvent_t start, stop;
     RT_HIP(hipEventCreate(&start));
     RT_HIP(hipEventCreate(&stop));
@@ -1165,7 +1165,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         }
         if (!finished)
             return failInvalid("bounds pass did not finish");
-        if (refineChoice() && n >= 64U)
+        if (allowRefine && refineChoice() && n >= 64U)
             RT_TRY(refineUpperLevels(n, stream, left, right, parent, first, last, bounds, arrivals, partials, order,
                                      idx[1 - result]));
     }
@@ -1300,6 +1300,13 @@ struct TopBuilder {
     std::vector<uint32_t> items;      // instance index per leaf item slot, contiguous per node
     std::vector<WideNode> nodes;
     uint32_t depth = 0;
+    // Levels the tree may have: what the traversal stack leaves after the deepest bottom-level tree.  Cuts by
+    // surface area are as lopsided as the boxes ask for (a chain of nested instances peels off a few per level),
+    // so a node whose groups would not fit the levels left below it is cut by count instead: eight even parts
+    // per node always fit count <= 8^levels.
+    uint32_t budget = 0xffffffffU;
+
+    static uint64_t capacityOf(uint32_t levels) { return levels >= 21U ? ~0ULL : 1ULL << (3U * levels); }
 
     struct Group {
         uint32_t first, count;
@@ -1339,9 +1346,9 @@ struct TopBuilder {
         });
     }
 
-    void split(const Group& g, Group& l, Group& r) {
+    void split(const Group& g, Group& l, Group& r, bool byCount = false) {
         uint32_t mid = g.first + g.count / 2;
-        if (g.count <= kSweepLimit) {
+        if (g.count <= kSweepLimit && !byCount) {
             int bestAxis = -1;
             uint32_t bestLeft = 0;
             float bestCost = INFINITY;
@@ -1398,22 +1405,31 @@ struct TopBuilder {
     void build(uint32_t self, const Group& group, uint32_t level) {
         depth = std::max(depth, level + 1);
         std::vector<Group> groups{group};
-        if (group.count > 1) {
+        const uint32_t below = budget > level + 1U ? budget - level - 1U : 0U;  // levels left for the children
+        for (int byCount = 0; byCount < 2 && group.count > 1; ++byCount) {
+            groups.assign(1, group);
             while (groups.size() < static_cast<size_t>(kWide)) {
                 int pick = -1;
                 float best = -1.0f;
-                for (size_t k = 0; k < groups.size(); ++k)
-                    if (groups[k].count > 1 && area(groups[k].box) > best) {
-                        best = area(groups[k].box);
+                for (size_t k = 0; k < groups.size(); ++k) {
+                    const float weight = byCount ? static_cast<float>(groups[k].count) : area(groups[k].box);
+                    if (groups[k].count > 1 && weight > best) {
+                        best = weight;
                         pick = static_cast<int>(k);
                     }
+                }
                 if (pick < 0)
                     break;
                 Group l, r;
-                split(groups[pick], l, r);
+                split(groups[pick], l, r, byCount != 0);
                 groups[pick] = l;
                 groups.insert(groups.begin() + pick + 1, r);
             }
+            bool fits = true;
+            for (const Group& g : groups)
+                fits = fits && (g.count == 1 || g.count <= capacityOf(below));
+            if (fits)
+                break;
         }
         Aabb all = emptyBox();
         for (const auto& g : groups)
@@ -1503,6 +1519,17 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     }
     TopBuilder builder(boxes);
     builder.nodes.resize(1);
+    // top + bottom levels the traversal stack can follow (fitsTraversalStack): the top tree takes what the deepest
+    // bottom-level tree leaves
+    uint32_t levels = 0;
+    while (fitsTraversalStack(levels + 1U, scene->blasDepth))
+        ++levels;
+    if (levels == 0U || count > TopBuilder::capacityOf(levels)) {
+        setLastError("tree too deep for the traversal stack: " + std::to_string(count) + " instances over bottom-level trees of " +
+                     std::to_string(scene->blasDepth) + " levels");
+        return RT_ERROR_OUT_OF_RANGE;
+    }
+    builder.budget = levels;
     builder.build(0, {0, count, builder.boxOf(0, count)}, 0);
     std::vector<InstanceRecord> ordered(count);
     if (builder.items.size() != count)
@@ -1569,8 +1596,20 @@ rt_status rt_blas_build(const void* vertices, uint32_t vertexCount, uint32_t ver
         return failInvalid("too many triangles");
     auto* blas = new rt_blas();
     RT_HIP(hipGetDevice(&blas->device));
-    const rt_status status = buildBlas(vertices, vertexCount, vertexStride, indices, triangleCount,
-                                       static_cast<hipStream_t>(stream), blas);
+    rt_status status = buildBlas(vertices, vertexCount, vertexStride, indices, triangleCount,
+                                 static_cast<hipStream_t>(stream), blas);
+    // The surface-area rebuild of the upper levels follows the boxes, not the count, and can come out deeper than
+    // the radix tree it replaced.  A tree that leaves the top level fewer than four of the levels the traversal
+    // stack can follow is built again without the rebuild, and the shallower of the two is kept.
+    if (status == RT_SUCCESS && refineChoice() && !fitsTraversalStack(4U, blas->depth)) {
+        auto* plain = new rt_blas();
+        plain->device = blas->device;
+        status = buildBlas(vertices, vertexCount, vertexStride, indices, triangleCount, static_cast<hipStream_t>(stream),
+                           plain, false);
+        if (status == RT_SUCCESS && plain->depth < blas->depth)
+            std::swap(blas, plain);
+        rt_blas_destroy(plain);
+    }
     if (status != RT_SUCCESS) {
         rt_blas_destroy(blas);
         return status;
