@@ -296,6 +296,21 @@ rt_status rt_render_sample_bands(rt_wavefront* wavefront, const rt_launch_params
 rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
                            uint32_t emissionCount, void* stream);
 
+/* rt_trace_photons for `passes` consecutive passes (params->photonPass, + 1, ...)
+ * of the same emission range in one go: the passes of the photon maps a long
+ * camera pass will gather from share every stage launch, whose cost at the late
+ * bounces is the same few slow photons however many passes ride along.  Pass k
+ * appends to lists[k] behind *counters[k] (device words the caller has zeroed)
+ * and, with keys and keys[k], writes bucket keys to keys[k]; all are host
+ * arrays of `passes` device pointers.  params->photons / photonCount are not
+ * used.  Photon i of pass k draws the streams seeded (i, photonPass + k)
+ * (src/device.cu:772), so every list equals that of a pass traced alone.  As many
+ * passes as the state holds (maxPaths / emissionCount) run side by side. */
+#define RT_MAX_PHOTON_PASSES 8
+rt_status rt_trace_photon_passes(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
+                                 uint32_t emissionCount, uint32_t passes, rt_photon* const* lists,
+                                 uint32_t* const* counters, uint32_t* const* keys, void* stream);
+
 /* Later rt_trace_photons calls on this state also write the bucket key of every
  * photon they store - photonBucket(photonCell(position, params->photonRadius),
  * params->photonBucketCount), src/photon_hash.cuh:10-24 - to keys[slot], slot

@@ -10,7 +10,7 @@ mkdir -p $OUT
 sha256sum raytracer_amd/librt_engine.so > $OUT/library.sha256
 export TMPDIR=/tmp
 # one region, one pass in flight: a launch overlaps no other, so its span is its own; passes of eight samples, as the default bench renders a 1080p frame
-BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --tiles 1 --in-flight 1 --batch 16"
+BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-extra-legs --tiles 1 --in-flight 1 --batch 16"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1

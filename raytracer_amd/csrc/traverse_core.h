@@ -66,6 +66,14 @@ namespace rt {
 #ifndef RT_TRACE_GRID_SCALE
 #define RT_TRACE_GRID_SCALE 1
 #endif
+// Whether the walk keeps the children of a node as one group - the node index its inner children start at plus
+// a byte of hit bits - instead of one stack entry per child with its entry distance: a node step then leaves at
+// most one entry behind, nothing is sorted, and the children are taken in the order the ray's direction octant
+// gives (Ylitie, Karras, Laine 2017); the price is that a child that has fallen behind the closest hit is only
+// found out when its node is read.  The leaf children that were hit are tested before the walk goes deeper.
+#ifndef RT_TRACE_GROUPS
+#define RT_TRACE_GROUPS 0
+#endif
 
 #ifndef RT_TRACE_BLOCK
 #define RT_TRACE_BLOCK 256
@@ -273,6 +281,12 @@ struct Traversal {
     uint32_t bestPrim, bestInst;
     int sp;
     uint32_t node;
+    // RT_TRACE_GROUPS: the node group the walk is taking children from (index of the first inner child of the
+    // node; bits 0-7 the inner children still to visit, in visiting order, bits 8-15 the node's inner mask), and
+    // the leaf group it is testing (index of the node's first item; bits 0-7 leaf slots still to do, 8-15 the
+    // node's leaf slots, 16-23 those of two items, bit 24: the first item of the slot in turn is done)
+    uint32_t groupBase, groupBits, leafBase, leafBits;
+    static constexpr uint32_t kLeafGroup = 0x80000000U;  // marks a leaf group on the stack
     // overflow stack: arrays owned by the kernel (kept out of this struct so that
     // the rest of the state is promoted to registers)
     uint32_t (&privateRef)[kPrivateStack];
@@ -308,7 +322,8 @@ struct Traversal {
         : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, idx(0.0f),
           idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), found(false),
           anyHit(false), floor(-1), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
-          bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
+          bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), groupBase(0), groupBits(0), leafBase(0), leafBits(0),
+          privateRef(spillRef), privateT(spillT),
           topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
 
     __device__ __forceinline__ void begin(const Ray& ray, float rayTmin, float rayTmax, uint32_t initInstance,
@@ -337,6 +352,10 @@ struct Traversal {
         bestInst = initInstance;
         sp = 0;
         node = 0;  // the top-level root
+        groupBase = 0;  // as a group: one child, the root itself (no inner bits below it, so its index is the base)
+        groupBits = 1;
+        leafBase = 0;
+        leafBits = 0;
     }
 
     __device__ __forceinline__ TraceResult result() const {
@@ -537,6 +556,229 @@ struct Traversal {
             }
         }
         node = refOf(key[0] & 7U);
+    }
+
+
+    // ---- RT_TRACE_GROUPS ---------------------------------------------------------------------------------------
+
+    __device__ __forceinline__ uint32_t octant() const {
+        return (idx < 0.0f ? 1U : 0U) | (idy < 0.0f ? 2U : 0U) | (idz < 0.0f ? 4U : 0U);
+    }
+    // bit j of the result is bit j ^ octant of `slots`: the builder puts a child that lies towards +x / +y / +z of
+    // its node's centre into a slot with bit 0 / 1 / 2 set, so that for a ray that travels towards -x (octant bit
+    // 0) the children come nearest first when slots are taken in ascending slot ^ octant
+    static __device__ __forceinline__ uint32_t inVisitingOrder(uint32_t slots, uint32_t oct) {
+        if (oct & 1U)
+            slots = ((slots & 0xaaU) >> 1) | ((slots & 0x55U) << 1);
+        if (oct & 2U)
+            slots = ((slots & 0xccU) >> 2) | ((slots & 0x33U) << 2);
+        if (oct & 4U)
+            slots = ((slots & 0xf0U) >> 4) | ((slots & 0x0fU) << 4);
+        return slots;
+    }
+    // bit `bit` of each of the eight bytes of lo : hi as an 8-bit mask
+    static __device__ __forceinline__ uint32_t byteBits(uint32_t lo, uint32_t hi, int bit) {
+        const uint32_t a = ((lo >> bit) & 0x01010101U) * 0x01020408U >> 24;
+        const uint32_t b = ((hi >> bit) & 0x01010101U) * 0x01020408U >> 24;
+        return (a & 15U) | (b & 15U) << 4;
+    }
+    __device__ __forceinline__ void pushGroup(uint32_t base, uint32_t bits) {
+        if (sp < kLdsStack) {
+            stackRef[sp * stride] = base;
+            ((LdsUint)stackT)[sp * stride] = bits;
+        } else if (sp < kMaxStack) {
+            privateRef[sp - kLdsStack] = base;
+            privateT[sp - kLdsStack] = __uint_as_float(bits);
+        }
+        ++sp;
+    }
+    __device__ __forceinline__ void leaveInstance() {
+        cur = world;
+        idx = __builtin_amdgcn_rcpf(cur.dx);
+        idy = __builtin_amdgcn_rcpf(cur.dy);
+        idz = __builtin_amdgcn_rcpf(cur.dz);
+        nodes = topNodes;
+        nodeLimit = topNodeLimit;
+        itemLimit = instanceLimit;
+        floor = -1;
+    }
+
+    // The node part of a turn: a lane whose leaf group is empty takes the next child of its node group (the
+    // stack's top group when its own is used up) and does that child's node step.
+    __device__ __forceinline__ void groupNodePhase() {
+        if (node == kDone || (leafBits & 0xffU))
+            return;
+        if (!(groupBits & 0xffU)) {
+            RT_SITE(2);
+            if (sp == 0) {
+                node = kDone;
+                return;
+            }
+            --sp;
+            if (sp < floor)
+                leaveInstance();
+            if (sp >= kMaxStack)
+                return;  // never pushed (guarded against on the host as well)
+            uint32_t base, bits;
+            if (sp < kLdsStack) {
+                base = stackRef[sp * stride];
+                bits = ((LdsUint)stackT)[sp * stride];
+            } else {
+                base = privateRef[sp - kLdsStack];
+                bits = __float_as_uint(privateT[sp - kLdsStack]);
+            }
+            if (bits & kLeafGroup) {
+                leafBase = base;
+                leafBits = bits & ~kLeafGroup;
+                return;
+            }
+            groupBase = base;
+            groupBits = bits;
+        }
+        const uint32_t oct = octant();
+        const uint32_t turn = static_cast<uint32_t>(__ffs(static_cast<int>(groupBits & 0xffU)) - 1);
+        const uint32_t slot = turn ^ oct;
+        groupBits &= ~(1U << turn);
+        const uint32_t inner = (groupBits >> 8) & 0xffU;
+        groupNodeStep(groupBase + __popc(inner & ((1U << slot) - 1U)), oct);
+    }
+
+    __device__ __forceinline__ void groupNodeStep(uint32_t index, uint32_t oct) {
+        RT_SITE(0);
+        RT_GUARD(index < nodeLimit);
+        if (COUNT)
+            ++counters.nodes;
+        GlobalUint4 np = globalView(nodes + index);
+        const uint4 n0 = np[0];
+        uint4 n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        uint32_t imask = n0.w >> 24;
+        if ((cur.dx * cur.dy) * cur.dz == 0.0f) {  // a ray parallel to an axis: see nodeStep
+            auto outsideSlab = [&](float direction, float origin, uint32_t corner, uint32_t exponent, uint32_t lo0,
+                                   uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint32_t {
+                if (direction != 0.0f)
+                    return 0U;
+                const float scale = __uint_as_float((exponent & 0xffU) << 23);
+                const float offset = __uint_as_float(corner) - origin;
+                const float margin = 0x1p-20f * ((fabsf(__uint_as_float(corner)) + fabsf(origin)) + 255.0f * scale);
+                uint32_t outside = 0U;
+#pragma unroll
+                for (int i = 0; i < kWide; ++i) {
+                    const int sh = 8 * (i & 3);
+                    const float qlo = static_cast<float>(((i < 4 ? lo0 : lo1) >> sh) & 0xffU);
+                    const float qhi = static_cast<float>(((i < 4 ? hi0 : hi1) >> sh) & 0xffU);
+                    if (fmaf(qlo, scale, offset) > margin || fmaf(qhi, scale, offset) < -margin)
+                        outside |= 1U << i;
+                }
+                return outside;
+            };
+            const uint32_t outside = outsideSlab(cur.dx, cur.ox, n0.x, n0.w, n2.x, n2.y, n3.z, n3.w) |
+                                     outsideSlab(cur.dy, cur.oy, n0.y, n0.w >> 8, n2.z, n2.w, n4.x, n4.y) |
+                                     outsideSlab(cur.dz, cur.oz, n0.z, n0.w >> 16, n3.x, n3.y, n4.z, n4.w);
+            auto bytesOf = [](uint32_t four) -> uint32_t {
+                return ((four & 1U) ? 0xffU : 0U) | ((four & 2U) ? 0xff00U : 0U) | ((four & 4U) ? 0xff0000U : 0U) |
+                       ((four & 8U) ? 0xff000000U : 0U);
+            };
+            const uint32_t b0 = bytesOf(outside & 15U), b1 = bytesOf(outside >> 4);
+            n2.x |= b0; n2.y |= b1; n2.z |= b0; n2.w |= b1; n3.x |= b0; n3.y |= b1;
+            n3.z &= ~b0; n3.w &= ~b1; n4.x &= ~b0; n4.y &= ~b1; n4.z &= ~b0; n4.w &= ~b1;
+        }
+        const float ax = __uint_as_float((n0.w & 0xffU) << 23) * idx;
+        const float ay = __uint_as_float(((n0.w >> 8) & 0xffU) << 23) * idy;
+        const float az = __uint_as_float(((n0.w >> 16) & 0xffU) << 23) * idz;
+        const float bx = (__uint_as_float(n0.x) - cur.ox) * idx;
+        const float by = (__uint_as_float(n0.y) - cur.oy) * idy;
+        const float bz = (__uint_as_float(n0.z) - cur.oz) * idz;
+        const float axn = ax * kShrink, ayn = ay * kShrink, azn = az * kShrink;
+        const float bxn = bx * kShrink, byn = by * kShrink, bzn = bz * kShrink;
+        const float axf = ax * kGrow, ayf = ay * kGrow, azf = az * kGrow;
+        const float bxf = bx * kGrow, byf = by * kGrow, bzf = bz * kGrow;
+        const float limit = bestT * kGrow;
+        const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;
+        const uint32_t xlo0 = nx ? n3.z : n2.x, xlo1 = nx ? n3.w : n2.y;
+        const uint32_t xhi0 = nx ? n2.x : n3.z, xhi1 = nx ? n2.y : n3.w;
+        const uint32_t ylo0 = ny ? n4.x : n2.z, ylo1 = ny ? n4.y : n2.w;
+        const uint32_t yhi0 = ny ? n2.z : n4.x, yhi1 = ny ? n2.w : n4.y;
+        const uint32_t zlo0 = nz ? n4.z : n3.x, zlo1 = nz ? n4.w : n3.y;
+        const uint32_t zhi0 = nz ? n3.x : n4.z, zhi1 = nz ? n3.y : n4.w;
+        uint32_t hitMask = 0;
+#pragma unroll
+        for (int i = 0; i < kWide; ++i) {
+            const int sh = 8 * (i & 3);
+            const float qxn = static_cast<float>(((i < 4 ? xlo0 : xlo1) >> sh) & 0xffU);
+            const float qxf = static_cast<float>(((i < 4 ? xhi0 : xhi1) >> sh) & 0xffU);
+            const float qyn = static_cast<float>(((i < 4 ? ylo0 : ylo1) >> sh) & 0xffU);
+            const float qyf = static_cast<float>(((i < 4 ? yhi0 : yhi1) >> sh) & 0xffU);
+            const float qzn = static_cast<float>(((i < 4 ? zlo0 : zlo1) >> sh) & 0xffU);
+            const float qzf = static_cast<float>(((i < 4 ? zhi0 : zhi1) >> sh) & 0xffU);
+            const float tn = fmaxf(fmaxf(fmaf(qxn, axn, bxn), fmaf(qyn, ayn, byn)), fmaxf(fmaf(qzn, azn, bzn), tminShrunk));
+            const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
+            hitMask |= tn <= tf ? (1U << i) : 0U;
+        }
+        // leaf slots: the item count of a meta byte sits in its bits 5-7 (one item: bit 5, two: bit 6); the bytes of
+        // inner and empty slots have none of them
+        static_assert(kMaxLeaf <= 2 || !RT_TRACE_GROUPS, "the leaf group keeps one bit per slot for a second item");
+        const uint32_t two = byteBits(n1.z, n1.w, 6);
+        const uint32_t leaves = (byteBits(n1.z, n1.w, 5) | two) & ~imask;
+        // the group this node's inner children are taken from replaces the one in hand, which waits on the stack
+        // when it has children left
+        if (groupBits & 0xffU)
+            pushGroup(groupBase, groupBits);
+        groupBase = n1.x;
+        groupBits = inVisitingOrder(hitMask & imask, oct) | imask << 8;
+        leafBase = n1.y;
+        leafBits = (hitMask & leaves) | leaves << 8 | two << 16;
+    }
+
+    // The leaf part of a turn: one item of the leaf group - a triangle, or in the top level an instance to enter.
+    __device__ __forceinline__ void groupLeafPhase() {
+        if (node == kDone || !(leafBits & 0xffU))
+            return;
+        const uint32_t slot = static_cast<uint32_t>(__ffs(static_cast<int>(leafBits & 0xffU)) - 1);
+        const uint32_t before = (1U << slot) - 1U;
+        const uint32_t leaves = (leafBits >> 8) & 0xffU, two = (leafBits >> 16) & 0xffU, second = (leafBits >> 24) & 1U;
+        const uint32_t item = leafBase + __popc(leaves & before) + __popc(two & before) + second;
+        if (!inBottom()) {
+            leafBits &= ~(1U << slot);
+            // what is left of this top-level node waits below the instance: its other instances, its inner children
+            if (leafBits & 0xffU)
+                pushGroup(leafBase, leafBits | kLeafGroup);
+            if (groupBits & 0xffU)
+                pushGroup(groupBase, groupBits);
+            leafBits = 0;
+            node = kLeafBit | item;
+            enterInstance();
+            if (node == kDone)
+                return;
+            groupBase = 0;  // the instance's root, as a group of one
+            groupBits = 1;
+            return;
+        }
+        RT_SITE(3);
+        if (COUNT)
+            ++counters.triangles;
+        RT_GUARD(item < itemLimit);
+        GlobalUint4 tp = globalView(triangles + item);
+        const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+        float t, u, v;
+        if (intersectTriangle(cur, shear, p0, p1, p2, tmin, bestT, t, u, v)) {
+            const uint32_t prim = p0.w;
+            if (t < bestT || instanceId < bestInst || (instanceId == bestInst && prim < bestPrim)) {
+                bestT = t;
+                bestU = u;
+                bestV = v;
+                bestPrim = prim;
+                bestInst = instanceId;
+                found = true;
+            }
+        }
+        if (anyHit && found) {
+            node = kDone;
+            return;
+        }
+        if (((two >> slot) & 1U) && !second)
+            leafBits |= 1U << 24;
+        else
+            leafBits &= ~((1U << 24) | (1U << slot));
     }
 
     // Top-level leaf: move the ray into the instance's object space.
@@ -832,6 +1074,9 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             uint32_t raySteps = 0;
             RT_SITE(5);
 #endif
+#if RT_TRACE_GROUPS
+            walk.groupNodePhase();
+#else
             // A turn is flat: one wide node for the lanes at one, then one stack entry
             // for the lanes that ran out of work (kPop), then the leaf code.  A loop
             // at any of these places makes the other lanes of the wave wait for its
@@ -839,6 +1084,7 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             // (three nodes per turn spilt 26-48 registers; this form spills none).
             if (!(walk.node & kLeafBit))
                 walk.nodeStep();
+#endif
 #if RT_TRACE_RIDING_REFILL
         }
         bool taking = false;
@@ -851,6 +1097,9 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
         }
         if (active) {
 #endif
+#if RT_TRACE_GROUPS
+            walk.groupLeafPhase();
+#else
             if (walk.node == kPop)
                 walk.node = walk.pop();
             if ((walk.node & 0xf0000000U) == kLeafBit)
@@ -872,6 +1121,7 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             // next turn at a node instead of spending that turn's node step idle
             if (walk.node == kPop)
                 walk.node = walk.pop();
+#endif
 #endif
         }
 #if RT_TRACE_SHARED_LEAVES

@@ -752,8 +752,10 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
 // ---- photon pass --------------------------------------------------------------
 
 // emitPhoton, device.cu:652-712, for emissions [first, first + count)
+// Path i of a launch over several passes is emission first + i % perPass of pass p.photonPass + i / perPass
+// (count = perPass x passes): the passes of consecutive photon maps share one launch of every stage.
 __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_params p, uint32_t first, uint32_t count,
-                                                                    Buffers b) {
+                                                                    uint32_t perPass, Buffers b) {
     __shared__ uint32_t slots[kSlotWords];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
@@ -761,7 +763,8 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
     uint32_t rng = 0;
     if (i < count) {
         b.photonFlags[i] = 0;
-        rng = seeded(first + i, p.photonPass);
+        const uint32_t pass = i / perPass;
+        rng = seeded(first + (i - pass * perPass), p.photonPass + pass);
         float choice = 0.0f;
         const rt_gpu_light* selected = pickLight(p, b.lightIndex, rng, choice);
         if (selected) {
@@ -916,28 +919,39 @@ __global__ __launch_bounds__(kShadeBlock) void photonShadeKernel(rt_launch_param
 
 // Appends the batch's stored photons behind *photonCount in emission order
 // (offsets = exclusive scan of the flags; offsets[count] = photons of the batch).
-// With `keys` the photon's bucket key goes to keys[slot] (photon_hash.cuh:10-24 at cell size p.photonRadius):
-// the position is in registers here, where the grid build would read the whole record again for it.
-__global__ __launch_bounds__(256) void photonCompactKernel(rt_launch_params p, uint32_t count, const uint32_t* offsets,
-                                                           Buffers b, uint32_t* keys) {
+// Where the photons of the passes of one launch go: a list, its counter and (optionally) its key array per pass.
+struct PhotonLists {
+    rt_photon* photons[RT_MAX_PHOTON_PASSES];
+    uint32_t* counter[RT_MAX_PHOTON_PASSES];
+    uint32_t* keys[RT_MAX_PHOTON_PASSES];
+};
+
+// Appends the batch's stored photons behind *counter of their pass in emission order (offsets = exclusive scan of
+// the flags over all paths, pass after pass; offsets[count] = photons of the batch).  With keys the photon's bucket
+// key goes to keys[slot] (photon_hash.cuh:10-24 at cell size p.photonRadius): the position is in registers here,
+// where the grid build would read the whole record again for it.
+__global__ __launch_bounds__(256) void photonCompactKernel(rt_launch_params p, uint32_t count, uint32_t perPass,
+                                                           const uint32_t* offsets, Buffers b, PhotonLists lists) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
         return;
     if (offsets[i + 1] != offsets[i]) {
-        const uint32_t slot = *p.photonCount + offsets[i];
+        const uint32_t pass = i / perPass;
+        const uint32_t slot = *lists.counter[pass] + (offsets[i] - offsets[pass * perPass]);
         if (slot < p.photonCapacity) {
             const rt_photon photon = b.photonTemp[i];
-            p.photons[slot] = photon;
-            if (keys)
-                keys[slot] = bucketOfPosition(photon.position.x, photon.position.y, photon.position.z, p.photonRadius,
-                                              p.photonBucketCount);
+            lists.photons[pass][slot] = photon;
+            if (lists.keys[pass])
+                lists.keys[pass][slot] = bucketOfPosition(photon.position.x, photon.position.y, photon.position.z,
+                                                          p.photonRadius, p.photonBucketCount);
         }
     }
 }
 
-__global__ void photonCountKernel(rt_launch_params p, uint32_t count, const uint32_t* offsets) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        *p.photonCount += offsets[count];
+__global__ void photonCountKernel(uint32_t perPass, uint32_t passes, const uint32_t* offsets, PhotonLists lists) {
+    const uint32_t pass = threadIdx.x;
+    if (blockIdx.x == 0 && pass < passes)
+        *lists.counter[pass] += offsets[(pass + 1U) * perPass] - offsets[pass * perPass];
 }
 
 }  // namespace
@@ -1451,49 +1465,87 @@ rt_status rt_render_sample_bands(rt_wavefront* w, const rt_launch_params* params
     return renderPaths(w, params, scene, map, seedSample, static_cast<hipStream_t>(stream));
 }
 
-rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint32_t firstEmission,
-                           uint32_t emissionCount, void* stream) {
+rt_status rt_trace_photon_passes(rt_wavefront* w, const rt_launch_params* params, uint32_t firstEmission,
+                                 uint32_t emissionCount, uint32_t passes, rt_photon* const* lists, uint32_t* const* counters,
+                                 uint32_t* const* keys, void* stream) {
     const rt_scene* scene = nullptr;
     RT_TRY(checkLaunch(w, params, scene));
-    if (!params->photons || !params->photonCount)
-        return failInvalid("launch parameters carry no photon buffers");
+    if (passes == 0 || passes > RT_MAX_PHOTON_PASSES || !lists || !counters)
+        return failInvalid("photon passes: between 1 and RT_MAX_PHOTON_PASSES, with a list and a counter each");
     if (!(w->uses & RT_WAVEFRONT_FOR_PHOTONS))
         return failInvalid("this wavefront state was created for camera passes only");
+    PhotonLists all{};
+    bool anyKeys = false;
+    for (uint32_t k = 0; k < passes; ++k) {
+        if (!lists[k] || !counters[k])
+            return failInvalid("launch parameters carry no photon buffers");
+        all.photons[k] = lists[k];
+        all.counter[k] = counters[k];
+        all.keys[k] = keys ? keys[k] : nullptr;
+        anyKeys = anyKeys || all.keys[k];
+    }
+    if (anyKeys && (!(params->photonRadius > 0.0f) || params->photonBucketCount == 0 ||
+                    (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
+        return failInvalid("photon keys asked for without a cell size (photonRadius) and a power-of-two bucket count");
     auto s = static_cast<hipStream_t>(stream);
     const Buffers b = buffersFor(w, params);
-    uint32_t* keys = w->photonKeys;
-    if (keys && (!(params->photonRadius > 0.0f) || params->photonBucketCount == 0 ||
-                 (params->photonBucketCount & (params->photonBucketCount - 1U)) != 0))
-        return failInvalid("photon keys asked for without a cell size (photonRadius) and a power-of-two bucket count");
-    uint32_t done = 0;
-    while (done < emissionCount) {
-        const uint32_t count = std::min(b.capacity, emissionCount - done);
-        const unsigned blocks = divUp(count, kShadeBlock);
-        const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
-        const uint2 limits = limitsOf(scene);
-        RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 8, s));
-        RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
-        hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, firstEmission + done,
-                           count, b);
-        for (uint32_t depth = 0; depth < 10U; ++depth) {
-            const int which = depth & 1U;
-            hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                               scene->instances, b, which, 0, limits);
-            hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, *params, scene->shadeInstances,
-                               scene->hitGroups, b, which, depth);
-            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);
+    // Whole passes side by side as long as the state holds them; a pass that does not fit by itself goes in pieces.
+    const uint32_t together = emissionCount ? std::min<uint64_t>(passes, b.capacity / emissionCount) : passes;
+    uint32_t pass = 0;
+    while (pass < passes) {
+        const uint32_t group = together >= 1U ? std::min(together, passes - pass) : 1U;
+        rt_launch_params launch = *params;
+        launch.photonPass = params->photonPass + pass;
+        PhotonLists mine{};
+        for (uint32_t k = 0; k < group; ++k) {
+            mine.photons[k] = all.photons[pass + k];
+            mine.counter[k] = all.counter[pass + k];
+            mine.keys[k] = all.keys[pass + k];
         }
-        // emission-ordered append: offsets = exclusive scan of the flags (with a
-        // trailing zero so that offsets[count] is the batch total)
-        RT_HIP(hipMemsetAsync(b.photonFlags + count, 0, sizeof(uint32_t), s));
-        RT_TRY(exclusiveScanU32(b.photonFlags, w->scanCounts, static_cast<size_t>(count) + 1, w->scanPartials, s));
-        hipLaunchKernelGGL(photonCompactKernel, dim3(divUp(count, 256)), dim3(256), 0, s, *params, count,
-                           w->scanCounts, b, keys);
-        hipLaunchKernelGGL(photonCountKernel, dim3(1), dim3(64), 0, s, *params, count, w->scanCounts);
-        RT_HIP(hipGetLastError());
-        done += count;
+        uint32_t done = 0;
+        while (done < emissionCount) {
+            const uint32_t perPass = together >= 1U ? emissionCount : std::min(b.capacity, emissionCount - done);
+            const uint32_t count = perPass * group;
+            const unsigned blocks = divUp(count, kShadeBlock);
+            const unsigned traceBlocks = std::min<unsigned>(divUp(count, kTraceBlock), persistentBlocks(w->device));
+            const uint2 limits = limitsOf(scene);
+            RT_HIP(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * 8, s));
+            RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
+            hipLaunchKernelGGL(photonGenerateKernel, dim3(blocks), dim3(kShadeBlock), 0, s, launch, firstEmission + done,
+                               count, perPass, b);
+            for (uint32_t depth = 0; depth < 10U; ++depth) {
+                const int which = depth & 1U;
+                hipLaunchKernelGGL(traceKernel<false>, dim3(traceBlocks), dim3(kTraceBlock), 0, s, scene->nodes,
+                                   scene->instances, b, which, 0, limits);
+                hipLaunchKernelGGL(photonShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, s, launch, scene->shadeInstances,
+                                   scene->hitGroups, b, which, depth);
+                hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(256), 0, s, b, which);
+            }
+            // emission-ordered append: offsets = exclusive scan of the flags (with a
+            // trailing zero so that offsets[count] is the batch total)
+            RT_HIP(hipMemsetAsync(b.photonFlags + count, 0, sizeof(uint32_t), s));
+            RT_TRY(exclusiveScanU32(b.photonFlags, w->scanCounts, static_cast<size_t>(count) + 1, w->scanPartials, s));
+            hipLaunchKernelGGL(photonCompactKernel, dim3(divUp(count, 256)), dim3(256), 0, s, launch, count, perPass,
+                               w->scanCounts, b, mine);
+            hipLaunchKernelGGL(photonCountKernel, dim3(1), dim3(64), 0, s, perPass, group, w->scanCounts, mine);
+            RT_HIP(hipGetLastError());
+            done += perPass;
+        }
+        pass += group;
     }
     return RT_SUCCESS;
+}
+
+rt_status rt_trace_photons(rt_wavefront* w, const rt_launch_params* params, uint32_t firstEmission,
+                           uint32_t emissionCount, void* stream) {
+    if (!w || !params)
+        return failInvalid("null pointer");
+    if (!params->photons || !params->photonCount)
+        return failInvalid("launch parameters carry no photon buffers");
+    rt_photon* list = params->photons;
+    uint32_t* counter = params->photonCount;
+    uint32_t* keys = w->photonKeys;
+    return rt_trace_photon_passes(w, params, firstEmission, emissionCount, 1, &list, &counter, &keys, stream);
 }
 
 }  // extern "C"

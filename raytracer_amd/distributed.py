@@ -167,31 +167,40 @@ class DistributedRenderer:
         self.stream = torch.cuda.Stream()
 
     def _photon_pass(self):
+        """The photon passes that are due - as many consecutive ones as the renderer traces together (those of the
+        maps its next camera pass gathers from): every rank traces its emission range of each, the lists of a
+        pass are exchanged into that pass's photon buffer, and every rank builds the same grids."""
         torch, r, R = self.torch, self.renderer, self.R
         first, last = shard_range(r.photon_emissions(), self.rank, self.world)
         capacity = r.photon_capacity()
-        r.begin_photon_pass()
-        # the local list goes to the staging area, so that every list, this rank's too, can be placed at
+        passes = r.begin_photon_passes(r.photon_passes_together())
+        # the local lists go to the staging areas, so that every list, this rank's too, can be placed at
         # its final offset of the photon buffer without a copy through a third buffer
-        stored = r.trace_photon_range(first, last - first, staging=True)
+        stored = r.trace_photon_range_passes(first, last - first, passes, staging=True)
         t0 = time.perf_counter()
-        staging = R.device_view(r.photon_staging_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
-        dest = R.device_view(r.photon_buffer(), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
+        totals, kept_all = [], []
         with torch.cuda.stream(self.stream):
-            if self.on_device:
-                counts = gather_counts(stored, self.group, "cuda")
-                kept, sent, received = exchange_photons_into(dest, staging, counts, self.group)
-            else:
-                counts = gather_counts(stored, self.group, "cpu")
-                host = torch.empty((min(sum(counts), capacity), PHOTON_FLOATS), dtype=torch.float32)
-                kept, sent, received = exchange_photons_into(host, staging[:stored].cpu(), counts, self.group)
-                dest[:kept].copy_(host[:kept])
-        # the grid build that follows runs on the renderer's photon stream: the merged list must be complete
+            for k in range(passes):
+                staging = R.device_view(r.photon_staging_buffer(k), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
+                dest = R.device_view(r.photon_buffer(k), capacity * 36, torch.float32).view(-1, PHOTON_FLOATS)
+                if self.on_device:
+                    counts = gather_counts(stored[k], self.group, "cuda")
+                    kept, sent, received = exchange_photons_into(dest, staging, counts, self.group)
+                else:
+                    counts = gather_counts(stored[k], self.group, "cpu")
+                    host = torch.empty((min(sum(counts), capacity), PHOTON_FLOATS), dtype=torch.float32)
+                    kept, sent, received = exchange_photons_into(host, staging[:stored[k]].cpu(), counts, self.group)
+                    dest[:kept].copy_(host[:kept])
+                totals.append(sum(counts))
+                kept_all.append((kept, sent, received))
+        # the grid builds that follow run on the renderer's photon stream: the merged lists must be complete
         self.stream.synchronize()
-        self.exchanges.append(dict(ms=(time.perf_counter() - t0) * 1e3, photons=sum(counts), kept=kept,
-                                   bytes_sent=sent, bytes_received=received))
-        r.finish_photon_pass(kept)
-        return sum(counts)
+        ms = (time.perf_counter() - t0) * 1e3 / passes
+        for k in range(passes):
+            kept, sent, received = kept_all[k]
+            self.exchanges.append(dict(ms=ms, photons=totals[k], kept=kept, bytes_sent=sent, bytes_received=received))
+        r.finish_photon_passes([kept for kept, _, _ in kept_all])
+        return sum(totals)
 
     def render(self):
         if self.renderer.photon_pass_due():

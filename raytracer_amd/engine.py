@@ -77,6 +77,7 @@ SYMBOLS = {
     "rt_render_sample_seeded": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "rt_render_sample_bands": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _u32, _vp]),
     "rt_trace_photons": (C.c_int, [_vp, _vp, _u32, _u32, _vp]),
+    "rt_trace_photon_passes": (C.c_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rt_wavefront_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
     "rt_wavefront_set_ray_share": (C.c_int, [_vp, _u32, _u32]),

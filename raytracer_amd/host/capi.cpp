@@ -450,6 +450,31 @@ int rth_renderer_trace_photon_range(rt::Renderer* r, uint32_t first, uint32_t co
 }
 void* rth_renderer_photon_buffer(rt::Renderer* r) { return r->photonBuffer(); }
 void* rth_renderer_photon_staging_buffer(rt::Renderer* r) { return r->photonStagingBuffer(); }
+// several consecutive photon passes at once (renderer.hpp: beginPhotonPasses and its companions)
+uint32_t rth_renderer_photon_passes_together(rt::Renderer* r) {
+    uint32_t count = 0;
+    guarded([&] { count = r->photonPassesTogether(); });
+    return count;
+}
+int rth_renderer_begin_photon_passes(rt::Renderer* r, uint32_t wanted, uint32_t* begun) {
+    return guarded([&] { *begun = r->beginPhotonPasses(wanted); });
+}
+int rth_renderer_trace_photon_range_passes(rt::Renderer* r, uint32_t first, uint32_t count, int intoStaging, uint32_t* stored) {
+    return guarded([&] { r->tracePhotonRangePasses(first, count, intoStaging != 0, stored); });
+}
+int rth_renderer_finish_photon_passes(rt::Renderer* r, const uint32_t* totals) {
+    return guarded([&] { r->finishPhotonPasses(totals); });
+}
+void* rth_renderer_photon_buffer_of(rt::Renderer* r, uint32_t pass) {
+    void* buffer = nullptr;
+    guarded([&] { buffer = r->photonBuffer(pass); });
+    return buffer;
+}
+void* rth_renderer_photon_staging_buffer_of(rt::Renderer* r, uint32_t pass) {
+    void* buffer = nullptr;
+    guarded([&] { buffer = r->photonStagingBuffer(pass); });
+    return buffer;
+}
 void* rth_renderer_output_buffer(rt::Renderer* r) { return r->outputBuffer(); }
 uint32_t rth_renderer_photon_capacity(rt::Renderer* r) { return r->photonCapacity(); }
 uint32_t rth_renderer_photon_emissions(rt::Renderer* r) { return r->photonEmissions(); }

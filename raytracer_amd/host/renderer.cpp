@@ -405,7 +405,8 @@ struct Renderer::Impl {
     // unsorted list, the counter and the sort's scratch serve one photon pass at a time, on the photon stream.
     DevicePool photonPool;
     struct PhotonBlocks {
-        std::size_t photons = 0, cellCounts = 0, counter = 0, scan = 0;
+        std::vector<std::size_t> photons;  // one unsorted list per pass that is traced together with others
+        std::size_t cellCounts = 0, counter = 0, scan = 0;  // counter: one word per list
         std::size_t scanBytes = 0;
     } photonAt;
     static constexpr std::uint32_t kNoEpoch = 0xffffffffU;
@@ -417,11 +418,13 @@ struct Renderer::Impl {
         std::vector<char> readRecorded;
     };
     std::vector<PhotonMap> maps;
-    std::uint32_t currentMap = 0;       // the map of the pass that is being built step by step (manual passes)
+    // the maps of the passes that are being built step by step (manual passes), one per list in use
+    std::vector<std::uint32_t> currentMaps{0};
     hipStream_t photonStream = nullptr;
-    std::uint32_t* storedOnHost = nullptr;  // pinned word the stored count of a manual pass is copied to
+    std::uint32_t* storedOnHost = nullptr;  // pinned words the stored counts of manual passes are copied to
     rt_wavefront* photonWavefront = nullptr;  // created by the first photon pass
     std::uint32_t photonWavefrontCapacity = 0;
+    std::uint64_t photonWavefrontAsked = 0;  // paths the state was last sized for, before the memory budget cut them
     float gatherRadius = 0.0f;
     bool caustics = false;
     bool overflowReported = false;
@@ -704,15 +707,18 @@ struct Renderer::Impl {
         if (!photonStream)
             hipOk(hipStreamCreate(&photonStream));
         if (!storedOnHost)
-            hipOk(hipHostMalloc(reinterpret_cast<void**>(&storedOnHost), sizeof(std::uint32_t), hipHostMallocDefault));
+            hipOk(hipHostMalloc(reinterpret_cast<void**>(&storedOnHost), sizeof(std::uint32_t) * RT_MAX_PHOTON_PASSES,
+                                hipHostMallocDefault));
         const std::uint32_t capacity = launch.photonCapacity, buckets = launch.photonBucketCount;
         Layout layout;
         const std::size_t listBytes = static_cast<std::size_t>(capacity) * sizeof(rt_photon);
         const std::size_t tableBytes = (static_cast<std::size_t>(buckets) + 1U) * sizeof(std::uint32_t);
         const std::size_t bitBytes = std::max<std::size_t>(1, buckets / 32U) * sizeof(std::uint32_t);
-        photonAt.photons = layout.take(listBytes);
+        photonAt.photons.assign(listsWanted(), 0);
+        for (std::size_t& list : photonAt.photons)
+            list = layout.take(listBytes);
         photonAt.cellCounts = layout.take(tableBytes);
-        photonAt.counter = layout.take(sizeof(std::uint32_t));
+        photonAt.counter = layout.take(sizeof(std::uint32_t) * RT_MAX_PHOTON_PASSES);
         // room for the sort of a full photon list (the reference sizes its scan for the buckets alone)
         photonAt.scanBytes = std::max(photonScanStorage(buckets), rt_photon_grid_scratch_bytes(capacity, buckets));
         photonAt.scan = layout.take(photonAt.scanBytes);
@@ -733,8 +739,8 @@ struct Renderer::Impl {
             for (hipEvent_t& event : map.read)
                 hipOk(hipEventCreateWithFlags(&event, hipEventDisableTiming));
         }
-        currentMap = 0;
-        launch.photons = photonPool.at<rt_photon>(photonAt.photons);
+        currentMaps.assign(1, 0U);
+        launch.photons = photonPool.at<rt_photon>(photonAt.photons[0]);
         launch.photonCount = photonPool.at<std::uint32_t>(photonAt.counter);
         launch.sortedPhotons = photonPool.at<const rt_photon>(maps[0].sorted);
         launch.photonCellStart = photonPool.at<const std::uint32_t>(maps[0].cellStart);
@@ -749,6 +755,14 @@ struct Renderer::Impl {
         const std::uint32_t perPass = batch % kPhotonRebuildInterval == 0U ? batch / kPhotonRebuildInterval
                                                                           : (batch + 6U) / kPhotonRebuildInterval;
         return static_cast<std::size_t>(std::max(perPass, 1U)) * depth;
+    }
+
+    // Photon passes traced together: those of the maps one camera pass gathers from (when its samples are whole
+    // groups of four), at most RT_MAX_PHOTON_PASSES.  Each has an unsorted list of its own.
+    std::size_t listsWanted() const {
+        if (!caustics || batch % kPhotonRebuildInterval != 0U)
+            return 1;
+        return std::min<std::size_t>(std::max<std::uint32_t>(batch / kPhotonRebuildInterval, 1U), RT_MAX_PHOTON_PASSES);
     }
 
     void shareLightIndex() {
@@ -806,7 +820,7 @@ struct Renderer::Impl {
 
     // The ring slot for the map of `epoch`, free to be overwritten: calls that wait for their pass and still read
     // the map the slot holds go out first, and the photon stream waits for the passes that gather from it.
-    PhotonMap& claimMap(std::uint32_t epoch) {
+    std::uint32_t claimMap(std::uint32_t epoch) {
         ensureParts();
         PhotonMap* map = &maps[epoch % maps.size()];
         if (pending > 0 && map->epoch != kNoEpoch && map->epoch >= sample / kPhotonRebuildInterval) {
@@ -819,48 +833,98 @@ struct Renderer::Impl {
                 map->readRecorded[k] = 0;
             }
         map->epoch = kNoEpoch;
-        currentMap = static_cast<std::uint32_t>(map - maps.data());
-        return *map;
+        return static_cast<std::uint32_t>(map - maps.data());
     }
 
-    void beginPhotonPass() {  // :742-745
+    std::uint32_t* counterOf(std::size_t list) const { return photonPool.at<std::uint32_t>(photonAt.counter) + list; }
+    rt_photon* listOf(std::size_t list) const { return photonPool.at<rt_photon>(photonAt.photons[list]); }
+
+    // Starts the passes of the next `wanted` photon maps (those of the groups of four samples from the next
+    // render() call on); fewer when the lists, the ring or the group's alignment do not allow more, at least one.
+    std::uint32_t beginPhotonPasses(std::uint32_t wanted) {  // :742-745
         reportOverflow(false);
         launch.photonRadius = gatherRadius;
-        claimMap(nextEpoch());
-        launch.photonPass = nextEpoch();
-        hipOk(hipMemsetAsync(photonPool.at<void>(photonAt.counter), 0, sizeof(std::uint32_t), photonStream));
+        ensureParts();
+        const std::uint32_t epoch = nextEpoch();
+        std::uint32_t count = std::min<std::uint32_t>(std::max(wanted, 1U), static_cast<std::uint32_t>(photonAt.photons.size()));
+        if (epoch % count != 0U || count > maps.size())
+            count = 1;  // groups start on a multiple of their size, so that the passes after them do as well
+        currentMaps.resize(count);
+        for (std::uint32_t k = 0; k < count; ++k)
+            currentMaps[k] = claimMap(epoch + k);
+        launch.photonPass = epoch;
+        hipOk(hipMemsetAsync(counterOf(0), 0, sizeof(std::uint32_t) * RT_MAX_PHOTON_PASSES, photonStream));
+        return count;
     }
+    void beginPhotonPass() { beginPhotonPasses(1); }
 
-    // The photon pass has wavefront state of its own, sized for a whole pass (at most 2^24 paths): every
-    // batch ends with the drain of its ray launches, so few large batches beat many frame-sized ones.
-    void ensurePhotonWavefront(std::uint32_t count) {
-        const std::uint32_t wanted = std::min<std::uint32_t>(std::max<std::uint32_t>(count, 1U), 1U << 24);
-        if (photonWavefront && photonWavefrontCapacity >= wanted)
+    // The photon passes have wavefront state of their own, sized for the emissions of the passes that run
+    // together (at most what a quarter of the free memory and 8 GiB hold, at least one pass of up to 2^24
+    // emissions, which goes in pieces when it is larger): every batch ends with the drain of its ray launches,
+    // so few large batches beat many small ones.
+    void ensurePhotonWavefront(std::uint32_t emissions, std::uint32_t passes) {
+        const std::uint64_t floorPaths = std::min<std::uint32_t>(std::max<std::uint32_t>(emissions, 1U), 1U << 24);
+        std::uint64_t wanted = std::max<std::uint64_t>(static_cast<std::uint64_t>(std::max(emissions, 1U)) * passes, floorPaths);
+        // (a state that was cut to the memory budget is not made again for the request it was cut from)
+        if (photonWavefront && (photonWavefrontCapacity >= wanted || photonWavefrontAsked >= wanted))
             return;
+        photonWavefrontAsked = wanted;
         hipOk(hipDeviceSynchronize());
         if (photonWavefront)
             rt_wavefront_destroy(photonWavefront);
         photonWavefront = nullptr;
-        engineOk(rt_wavefront_create_for(wanted, RT_WAVEFRONT_FOR_PHOTONS, &photonWavefront), "rt_wavefront_create_for");
+        photonWavefrontCapacity = 0;
+        std::size_t freeBytes = 0, totalBytes = 0;
+        hipOk(hipMemGetInfo(&freeBytes, &totalBytes));
+        const std::uint64_t budget = std::min<std::uint64_t>(8ULL << 30, freeBytes / 4U);
+        while (wanted > floorPaths) {  // whole passes
+            std::size_t bytes = 0;
+            engineOk(rt_wavefront_state_bytes(static_cast<std::uint32_t>(std::min<std::uint64_t>(wanted, 0xffffffffULL)),
+                                              RT_WAVEFRONT_FOR_PHOTONS, &bytes),
+                     "rt_wavefront_state_bytes");
+            if (wanted <= 0xffffffffULL && bytes <= budget)
+                break;
+            wanted -= std::max(emissions, 1U);
+        }
+        wanted = std::max(wanted, floorPaths);
+        engineOk(rt_wavefront_create_for(static_cast<std::uint32_t>(wanted), RT_WAVEFRONT_FOR_PHOTONS, &photonWavefront),
+                 "rt_wavefront_create_for");
         engineOk(rt_wavefront_set_light_index(photonWavefront, lightIndex, launch.lightCount), "rt_wavefront_set_light_index");
-        photonWavefrontCapacity = wanted;
+        photonWavefrontCapacity = static_cast<std::uint32_t>(wanted);
     }
 
-    // One range of a pass for a driver that merges the lists of several GPUs: waits for the tracer (not for
-    // the samples that are still rendering on other streams) and returns what this GPU stored (:746-769).
-    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {
-        ensurePhotonWavefront(count);
-        rt_launch_params pass = launch;
-        if (intoStaging)
-            pass.photons = photonPool.at<rt_photon>(maps[currentMap].sorted);
-        engineOk(rt_wavefront_set_photon_keys(photonWavefront, nullptr), "rt_wavefront_set_photon_keys");
-        engineOk(rt_trace_photons(photonWavefront, &pass, first, count, photonStream), "rt_trace_photons");
-        hipOk(hipMemcpyAsync(storedOnHost, photonPool.at<void>(photonAt.counter), sizeof(std::uint32_t), hipMemcpyDeviceToHost,
-                             photonStream));
+    // The emissions [first, first + count) of every pass that has been begun, on the photon stream.
+    void tracePasses(std::uint32_t first, std::uint32_t count, bool intoStaging, bool withKeys) {
+        const std::uint32_t passes = static_cast<std::uint32_t>(currentMaps.size());
+        ensurePhotonWavefront(count, passes);
+        rt_photon* lists[RT_MAX_PHOTON_PASSES] = {};
+        std::uint32_t* counters[RT_MAX_PHOTON_PASSES] = {};
+        std::uint32_t* keys[RT_MAX_PHOTON_PASSES] = {};
+        for (std::uint32_t k = 0; k < passes; ++k) {
+            lists[k] = intoStaging ? photonPool.at<rt_photon>(maps[currentMaps[k]].sorted) : listOf(k);
+            counters[k] = counterOf(k);
+            keys[k] = withKeys && passes == 1U ? photonKeys : nullptr;  // the sort's scratch holds the keys of one list
+        }
+        engineOk(rt_trace_photon_passes(photonWavefront, &launch, first, count, passes, lists, counters, keys, photonStream),
+                 "rt_trace_photon_passes");
+    }
+
+    // One range of the begun passes for a driver that merges the lists of several GPUs: waits for the tracer (not
+    // for the samples that are still rendering on other streams) and reports what this GPU stored per pass (:746-769).
+    void tracePhotonRangePasses(std::uint32_t first, std::uint32_t count, bool intoStaging, std::uint32_t* stored) {
+        tracePasses(first, count, intoStaging, false);
+        const std::size_t passes = currentMaps.size();
+        hipOk(hipMemcpyAsync(storedOnHost, counterOf(0), sizeof(std::uint32_t) * passes, hipMemcpyDeviceToHost, photonStream));
         hipOk(hipStreamSynchronize(photonStream));
-        const std::uint32_t stored = *storedOnHost;
-        warnIfOverfull(stored);
-        return std::min(stored, launch.photonCapacity);
+        for (std::size_t k = 0; k < passes; ++k) {
+            warnIfOverfull(storedOnHost[k]);
+            stored[k] = std::min(storedOnHost[k], launch.photonCapacity);
+        }
+    }
+    std::uint32_t tracePhotonRange(std::uint32_t first, std::uint32_t count, bool intoStaging) {
+        std::uint32_t stored[RT_MAX_PHOTON_PASSES] = {};
+        tracePhotonRangePasses(first, count, intoStaging, stored);
+        return stored[0];
     }
 
     void warnIfOverfull(std::uint32_t stored) {
@@ -871,46 +935,49 @@ struct Renderer::Impl {
         }
     }
 
-    void finishPhotonPass(std::uint32_t stored) {  // :770-776
-        stored = std::min(stored, launch.photonCapacity);
-        PhotonMap& map = maps[currentMap];
-        engineOk(rt_build_photon_grid_async(launch.photons, stored, launch.photonRadius, launch.photonBucketCount,
-                                            photonPool.at<std::uint32_t>(photonAt.cellCounts),
-                                            photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
-                                            photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted), photonStream),
-                 "buildPhotonGrid");
-        sealMap(map);
+    void finishPhotonPasses(const std::uint32_t* totals) {  // :770-776
+        for (std::size_t k = 0; k < currentMaps.size(); ++k) {
+            const std::uint32_t stored = std::min(totals[k], launch.photonCapacity);
+            PhotonMap& map = maps[currentMaps[k]];
+            engineOk(rt_build_photon_grid_async(listOf(k), stored, launch.photonRadius, launch.photonBucketCount,
+                                                photonPool.at<std::uint32_t>(photonAt.cellCounts),
+                                                photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
+                                                photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted), photonStream),
+                     "buildPhotonGrid");
+            sealMap(map, launch.photonPass + static_cast<std::uint32_t>(k));
+        }
     }
+    void finishPhotonPass(std::uint32_t stored) { finishPhotonPasses(&stored); }
 
     // Bucket bits of a freshly built map, the event its readers wait for, and the group it now serves.
-    void sealMap(PhotonMap& map) {
+    void sealMap(PhotonMap& map, std::uint32_t epoch) {
         engineOk(rt_photon_bucket_bitmap(photonPool.at<const std::uint32_t>(map.cellStart), launch.photonBucketCount,
                                          photonPool.at<std::uint32_t>(map.bucketBits), photonStream),
                  "rt_photon_bucket_bitmap");
         hipOk(hipEventRecord(map.built, photonStream));
-        map.epoch = launch.photonPass;
+        map.epoch = epoch;
     }
 
-    // The whole pass of renderer.cpp:741-777 without a wait: the reference synchronises behind the tracer and
-    // reads the stored count back (:753-758) to clamp it (:769) and hand it to the grid build (:770-775); here the
-    // count stays in device memory, the build reads and clamps it there, the tracer writes every photon's bucket
-    // key beside it, and the warning of :762-768 is printed when a copy of the count has reached the host by
-    // itself.  The host runs on to the samples that read the new map.
+    // The passes of renderer.cpp:741-777 without a wait: the reference synchronises behind the tracer and reads the
+    // stored count back (:753-758) to clamp it (:769) and hand it to the grid build (:770-775); here the count stays
+    // in device memory, the build reads and clamps it there, the tracer writes every photon's bucket key beside it
+    // (a single pass) and the warning of :762-768 is printed when a copy of the count has reached the host by
+    // itself.  The passes of all the maps the next camera pass gathers from are traced together.  The host runs on
+    // to the samples that read the new maps.
     void photonPassInFlight() {
-        beginPhotonPass();
-        PhotonMap& map = maps[currentMap];
-        ensurePhotonWavefront(launch.photonEmissions);
-        engineOk(rt_wavefront_set_photon_keys(photonWavefront, photonKeys), "rt_wavefront_set_photon_keys");
-        engineOk(rt_trace_photons(photonWavefront, &launch, 0, launch.photonEmissions, photonStream), "rt_trace_photons");
-        const std::uint32_t* counter = photonPool.at<const std::uint32_t>(photonAt.counter);
-        watchStoredCount(counter);
+        const std::uint32_t passes = beginPhotonPasses(static_cast<std::uint32_t>(photonAt.photons.size()));
+        tracePasses(0, launch.photonEmissions, false, true);
         const std::uint32_t most = std::min(launch.photonCapacity, launch.photonEmissions);
-        engineOk(rt_build_photon_grid_counted(launch.photons, counter, most, launch.photonRadius, launch.photonBucketCount,
-                                              photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
-                                              photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted), photonKeys ? 1 : 0,
-                                              photonStream),
-                 "rt_build_photon_grid_counted");
-        sealMap(map);
+        for (std::uint32_t k = 0; k < passes; ++k) {
+            PhotonMap& map = maps[currentMaps[k]];
+            watchStoredCount(counterOf(k));
+            engineOk(rt_build_photon_grid_counted(listOf(k), counterOf(k), most, launch.photonRadius, launch.photonBucketCount,
+                                                  photonPool.at<std::uint32_t>(map.cellStart), photonPool.at<void>(photonAt.scan),
+                                                  photonAt.scanBytes, photonPool.at<rt_photon>(map.sorted),
+                                                  passes == 1U && photonKeys ? 1 : 0, photonStream),
+                     "rt_build_photon_grid_counted");
+            sealMap(map, launch.photonPass + k);
+        }
     }
 
     void watchStoredCount(const std::uint32_t* counter) {
@@ -1121,7 +1188,8 @@ struct Renderer::Impl {
                 batch /= 2;
             }
         }
-        if (maps.size() != mapsWanted() || (!maps.empty() && maps.front().read.size() != parts.size()))
+        if (maps.size() != mapsWanted() || photonAt.photons.size() != listsWanted() ||
+            (!maps.empty() && maps.front().read.size() != parts.size()))
             allocateMaps(mapsWanted());
         shareLightIndex();
     }
@@ -1273,8 +1341,26 @@ void Renderer::beginPhotonPass() { impl_->beginPhotonPass(); }
 std::uint32_t Renderer::tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging) {
     return impl_->tracePhotonRange(firstEmission, emissionCount, intoStaging);
 }
-void* Renderer::photonBuffer() const { return impl_->photonPool.at<void>(impl_->photonAt.photons); }
-void* Renderer::photonStagingBuffer() const { return impl_->photonPool.at<void>(impl_->maps[impl_->currentMap].sorted); }
+void* Renderer::photonBuffer(std::uint32_t pass) const {
+    if (pass >= impl_->photonAt.photons.size())
+        raise("photon buffer: no such pass");
+    return impl_->listOf(pass);
+}
+void* Renderer::photonStagingBuffer(std::uint32_t pass) const {
+    if (pass >= impl_->currentMaps.size())
+        raise("photon staging buffer: no such pass");
+    return impl_->photonPool.at<void>(impl_->maps[impl_->currentMaps[pass]].sorted);
+}
+std::uint32_t Renderer::beginPhotonPasses(std::uint32_t wanted) { return impl_->beginPhotonPasses(wanted); }
+std::uint32_t Renderer::photonPassesTogether() const {
+    impl_->ensureParts();
+    return static_cast<std::uint32_t>(impl_->photonAt.photons.size());
+}
+void Renderer::tracePhotonRangePasses(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging,
+                                      std::uint32_t* stored) {
+    impl_->tracePhotonRangePasses(firstEmission, emissionCount, intoStaging, stored);
+}
+void Renderer::finishPhotonPasses(const std::uint32_t* totals) { impl_->finishPhotonPasses(totals); }
 std::uint32_t Renderer::photonCapacity() const { return impl_->launch.photonCapacity; }
 std::uint32_t Renderer::photonEmissions() const { return impl_->launch.photonEmissions; }
 void Renderer::finishPhotonPass(std::uint32_t totalPhotons) { impl_->finishPhotonPass(totalPhotons); }

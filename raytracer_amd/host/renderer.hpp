@@ -95,8 +95,18 @@ public:
     // holds nothing between beginPhotonPass() and finishPhotonPass(), so that a driver can receive
     // every GPU's photons, its own included, straight at their final place in photonBuffer().
     std::uint32_t tracePhotonRange(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging = false);
-    void* photonBuffer() const;           // device, photonCapacity() * 36 bytes
-    void* photonStagingBuffer() const;    // device, photonCapacity() * 36 bytes
+    void* photonBuffer(std::uint32_t pass = 0) const;           // device, photonCapacity() * 36 bytes
+    void* photonStagingBuffer(std::uint32_t pass = 0) const;    // device, photonCapacity() * 36 bytes
+    // The same three steps for several consecutive passes at once - those of the photon maps one camera pass of
+    // many samples gathers from - which then share every launch of the tracer: beginPhotonPasses() starts up to
+    // `wanted` passes (at most photonPassesTogether(), one when the next pass is no multiple of the count) and
+    // returns how many; tracePhotonRangePasses() traces the range for each and reports the stored count per pass;
+    // photonBuffer(k) / photonStagingBuffer(k) are the buffers of pass k; finishPhotonPasses() takes the total
+    // per pass.
+    std::uint32_t photonPassesTogether() const;
+    std::uint32_t beginPhotonPasses(std::uint32_t wanted);
+    void tracePhotonRangePasses(std::uint32_t firstEmission, std::uint32_t emissionCount, bool intoStaging, std::uint32_t* stored);
+    void finishPhotonPasses(const std::uint32_t* totals);
     std::uint32_t photonCapacity() const;
     std::uint32_t photonEmissions() const;
     void finishPhotonPass(std::uint32_t totalPhotons);

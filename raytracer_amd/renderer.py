@@ -124,6 +124,12 @@ _SIG = {
     "rth_renderer_photon_pass_due": (C.c_int, [_vp]),
     "rth_renderer_begin_photon_pass": (C.c_int, [_vp]),
     "rth_renderer_trace_photon_range": (C.c_int, [_vp, _u32, _u32, C.c_int, C.POINTER(_u32)]),
+    "rth_renderer_photon_passes_together": (_u32, [_vp]),
+    "rth_renderer_begin_photon_passes": (C.c_int, [_vp, _u32, C.POINTER(_u32)]),
+    "rth_renderer_trace_photon_range_passes": (C.c_int, [_vp, _u32, _u32, C.c_int, C.POINTER(_u32)]),
+    "rth_renderer_finish_photon_passes": (C.c_int, [_vp, C.POINTER(_u32)]),
+    "rth_renderer_photon_buffer_of": (_vp, [_vp, _u32]),
+    "rth_renderer_photon_staging_buffer_of": (_vp, [_vp, _u32]),
     "rth_renderer_photon_buffer": (_vp, [_vp]),
     "rth_renderer_photon_staging_buffer": (_vp, [_vp]),
     "rth_renderer_output_buffer": (_vp, [_vp]),
@@ -457,11 +463,32 @@ class Renderer:
         _check(load().rth_renderer_trace_photon_range(self.handle, first, count, int(staging), C.byref(stored)))
         return stored.value
 
-    def photon_buffer(self):
-        return int(load().rth_renderer_photon_buffer(self.handle) or 0)
+    def photon_buffer(self, which=0):
+        return int(load().rth_renderer_photon_buffer_of(self.handle, which) or 0)
 
-    def photon_staging_buffer(self):
-        return int(load().rth_renderer_photon_staging_buffer(self.handle) or 0)
+    def photon_staging_buffer(self, which=0):
+        return int(load().rth_renderer_photon_staging_buffer_of(self.handle, which) or 0)
+
+    def photon_passes_together(self):
+        """Consecutive photon passes begin_photon_passes() can start at once (those of the maps one camera pass
+        gathers from)."""
+        return int(load().rth_renderer_photon_passes_together(self.handle))
+
+    def begin_photon_passes(self, wanted):
+        """Starts up to `wanted` consecutive passes; returns how many were started (at least one)."""
+        begun = _u32(0)
+        _check(load().rth_renderer_begin_photon_passes(self.handle, wanted, C.byref(begun)))
+        return int(begun.value)
+
+    def trace_photon_range_passes(self, first, count, passes, staging=False):
+        """The emission range for every begun pass; returns the stored count per pass."""
+        stored = (_u32 * 8)()
+        _check(load().rth_renderer_trace_photon_range_passes(self.handle, first, count, int(staging), stored))
+        return [int(stored[k]) for k in range(passes)]
+
+    def finish_photon_passes(self, totals):
+        values = (_u32 * 8)(*totals)
+        _check(load().rth_renderer_finish_photon_passes(self.handle, values))
 
     def output_buffer(self):
         return int(load().rth_renderer_output_buffer(self.handle) or 0)

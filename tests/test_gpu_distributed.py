@@ -34,8 +34,9 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
             dr.render()
         image = dr.linear_pixels()
         np.save(os.path.join(out_dir, f"image{rank}.npy"), image)
-        # two photon passes (before samples 0 and 4), each with its exchange record
-        assert len(dr.exchanges) == 2 and all(e["kept"] == e["photons"] > 1000 for e in dr.exchanges)
+        # the photon passes of samples 0-3 and 4-7 at least (the passes of the maps one camera pass gathers from are
+        # traced together, so more may have been made), each with its exchange record
+        assert len(dr.exchanges) >= 2 and all(e["kept"] == e["photons"] > 1000 for e in dr.exchanges)
         if world == 1:
             assert all(e["bytes_sent"] == 0 and e["bytes_received"] == 0 for e in dr.exchanges)
         else:

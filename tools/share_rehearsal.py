@@ -35,18 +35,20 @@ for share in args.shares:
     if args.in_flight:
         r.set_concurrent_tiles(1, args.in_flight)
     r.set_row_interleave(0, share)
-    full = 0
+    full = []
     if final and share > 1:
         r.set_manual_photon_passes(True)
-        r.begin_photon_pass()
-        full = r.trace_photon_range(0, r.photon_emissions())  # the merged list of a pass, left in the photon buffer
-        r.finish_photon_pass(full)
+        passes = r.begin_photon_passes(r.photon_passes_together())
+        # the merged lists of the passes that run together, left in their photon buffers
+        full = r.trace_photon_range_passes(0, r.photon_emissions(), passes)
+        r.finish_photon_passes(full)
+        together = passes
 
     def step():
         if final and share > 1 and r.photon_pass_due():
-            r.begin_photon_pass()
-            r.trace_photon_range(0, r.photon_emissions() // share, staging=True)
-            r.finish_photon_pass(full)
+            passes = r.begin_photon_passes(together)
+            r.trace_photon_range_passes(0, r.photon_emissions() // share, passes, staging=True)
+            r.finish_photon_passes(full[:passes])
         r.render()
 
     for _ in range(64):
@@ -58,6 +60,7 @@ for share in args.shares:
     r.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     first = first or ms
-    print(f"{args.workload} 1/{share} of the bands, passes of {r.sample_batch()} samples, {r.samples_in_flight()} in flight: "
+    print(f"{args.workload} 1/{share} of the bands, passes of {r.sample_batch()} samples, {r.samples_in_flight()} in flight"
+          + (f", {r.photon_passes_together()} photon passes together" if final else "") + ": "
           f"{ms:.3f} ms per sample, efficiency {first / (ms * share):.2f}", flush=True)
     del r
