@@ -435,6 +435,8 @@ def soup_leg(eng, sizes, rays=1 << 24, repeats=3):
     the HBM roofline by algorithmic bytes (52 B per ray + 80 B per node visited + 36 B per triangle tested)."""
     import torch
     out = []
+    # a small build first: the first one of a process also loads the build kernels, which is no part of a build time
+    eng.Blas(torch.rand((3 * 4096, 3), device="cuda"), torch.arange(3 * 4096, dtype=torch.int32, device="cuda").reshape(-1, 3))
     for n in sizes:
         need = n * (36 + 12 + 48 + 40) * 2 + rays * 64  # triangles, indices, packed copy, nodes and sort scratch; rays
         if torch.cuda.mem_get_info()[0] < need + (8 << 30):

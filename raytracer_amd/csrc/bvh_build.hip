@@ -224,14 +224,33 @@ __global__ __launch_bounds__(256) void leafBoundsKernel(const Box4* boxes, const
 //
 // level 0 lists the parents both of whose children are leaves; counts[k] is the
 // length of list k and is zeroed before the first launch.
+// A slot of `list` for every lane of the wave with `wants` set: one atomic per wave on the list's length instead
+// of one per lane (a hundred million lanes adding to one word queue up behind each other: 18 of the 126 ms of a
+// 100 M triangle build).  The order of a list does not enter the bounds.
+__device__ inline uint32_t appendSlot(bool wants, uint32_t* length) {
+    const unsigned long long votes = __ballot(wants);
+    if (votes == 0ULL)
+        return 0U;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __ffsll(static_cast<long long>(votes)) - 1)
+        base = atomicAdd(length, static_cast<uint32_t>(__popcll(votes)));
+    base = __shfl(base, __ffsll(static_cast<long long>(votes)) - 1, 64);
+    return base + __popcll(votes & ((1ULL << lane) - 1ULL));
+}
+
 __global__ __launch_bounds__(256) void refitLeavesKernel(const uint32_t* parent, uint32_t n, uint32_t* arrivals,
                                                          uint32_t* list, uint32_t* counts) {
     const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (k >= n || n < 2)
-        return;
-    const uint32_t node = parent[(n - 1U) + k];
-    if (atomicAdd(&arrivals[node], 1U) == 1U)
-        list[atomicAdd(&counts[0], 1U)] = node;
+    uint32_t node = 0;
+    bool ready = false;
+    if (k < n && n >= 2) {
+        node = parent[(n - 1U) + k];
+        ready = atomicAdd(&arrivals[node], 1U) == 1U;
+    }
+    const uint32_t slot = appendSlot(ready, &counts[0]);
+    if (ready)
+        list[slot] = node;
 }
 
 __global__ __launch_bounds__(256) void refitLevelKernel(const uint32_t* left, const uint32_t* right,
@@ -239,13 +258,21 @@ __global__ __launch_bounds__(256) void refitLevelKernel(const uint32_t* left, co
                                                         const uint32_t* listIn, uint32_t* listOut, uint32_t* counts,
                                                         uint32_t level) {
     const uint32_t ready = counts[level];
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < ready;
-         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const uint32_t node = listIn[i];
-        bounds[node] = merge(bounds[left[node]], bounds[right[node]]);
-        const uint32_t up = parent[node];
-        if (up != kNoHit && atomicAdd(&arrivals[up], 1U) == 1U)
-            listOut[atomicAdd(&counts[level + 1U], 1U)] = up;
+    // whole waves go round together, so that the wave-wide append sees every lane
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t base = static_cast<size_t>(blockIdx.x) * blockDim.x; base < ready; base += stride) {
+        const size_t i = base + threadIdx.x;
+        uint32_t up = kNoHit;
+        bool next = false;
+        if (i < ready) {
+            const uint32_t node = listIn[i];
+            bounds[node] = merge(bounds[left[node]], bounds[right[node]]);
+            up = parent[node];
+            next = up != kNoHit && atomicAdd(&arrivals[up], 1U) == 1U;
+        }
+        const uint32_t slot = appendSlot(next, &counts[level + 1U]);
+        if (next)
+            listOut[slot] = up;
     }
 }
 
@@ -468,6 +495,19 @@ struct UpperNode {
     Box4 box;
     uint32_t id, left, right, triangles;
 };
+
+// Surface area x triangles of every radix-tree node above the clusters, in the order of `ids`: what the tree that
+// is there costs, to hold against the cost of the rebuilt one.
+__global__ __launch_bounds__(256) void upperCostKernel(const uint32_t* ids, uint32_t count, const uint32_t* first,
+                                                       const uint32_t* last, const Box4* bounds, float* cost) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint32_t id = ids[k];
+    const Box4 b = bounds[id];
+    const float x = b.hi.x - b.lo.x, y = b.hi.y - b.lo.y, z = b.hi.z - b.lo.z;
+    cost[k] = (x * y + y * z + z * x) * static_cast<float>(last[id] - first[id] + 1U);
+}
 
 __global__ __launch_bounds__(256) void upperScatterKernel(const UpperNode* nodes, uint32_t count, uint32_t* left,
                                                           uint32_t* right, uint32_t* parent, Box4* bounds,
@@ -953,8 +993,14 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
                        roots.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(),
                        clusterRecords.as<ClusterRecord>());
     hipLaunchKernelGGL(upperIdsKernel, dim3(blocks), dim3(256), 0, stream, n, upper.as<uint32_t>(), upperIds.as<uint32_t>());
+    DeviceBuffer upperCost;
+    RT_TRY(upperCost.allocate(sizeof(float) * upperCount));
+    hipLaunchKernelGGL(upperCostKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperIds.as<uint32_t>(), upperCount,
+                       first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(), upperCost.as<float>());
     std::vector<ClusterRecord> clusters(clusterCount);
     std::vector<uint32_t> ids(upperCount);
+    std::vector<float> oldCost(upperCount);
+    RT_HIP(hipMemcpyAsync(oldCost.data(), upperCost.data, sizeof(float) * upperCount, hipMemcpyDeviceToHost, stream));
     RT_HIP(hipMemcpyAsync(clusters.data(), clusterRecords.data, sizeof(ClusterRecord) * clusterCount, hipMemcpyDeviceToHost,
                           stream));
     RT_HIP(hipMemcpyAsync(ids.data(), upperIds.data, sizeof(uint32_t) * upperCount, hipMemcpyDeviceToHost, stream));
@@ -968,6 +1014,24 @@ rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, 
     if (builder.nodes.size() != upperCount)
         return failInvalid("upper tree has the wrong size");
     mark("surface-area build (host)");
+    // The rebuilt tree is only put in place where it is the cheaper one by the measure it was built for (surface
+    // area x triangles over its nodes, summed in a fixed order so that every run decides alike): on triangles spread
+    // evenly the radix tree's median cuts are the surface-area cuts already, and renumbering a hundred million
+    // leaves for nothing is a fifth of the build.  RT_BLAS_REFINE=always skips the comparison.
+    {
+        double before = 0.0, after = 0.0;
+        for (float c : oldCost)
+            before += c;
+        for (const UpperBuilder::Node& node : builder.nodes)
+            after += static_cast<double>(node.box.area()) * node.triangles;
+        if (timing)
+            std::fprintf(stderr, "  refine cost of the upper tree: radix %.6g, rebuilt %.6g (%.4f)\n", before, after,
+                         before > 0.0 ? after / before : 0.0);
+        const char* choice = std::getenv("RT_BLAS_REFINE");
+        const bool always = choice && std::strcmp(choice, "always") == 0;
+        if (!always && !(after < before * 0.98))
+            return RT_SUCCESS;
+    }
     auto reference = [&](uint32_t r) {
         return (r & UpperBuilder::kClusterBit) ? clusters[r & ~UpperBuilder::kClusterBit].node : ids[r];
     };
