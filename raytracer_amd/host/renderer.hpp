@@ -62,8 +62,8 @@ public:
     // on a stream of its own, their accumulation steps chained in sample order: for small frames or
     // small shares of one, where a single sample's launches cannot fill the GPU.  Restarts the
     // accumulation.
-    // samplesInFlight 0 leaves the choice to the renderer: two passes in flight, four with the final
-    // profile (whose passes are single samples).  The default is one region and that choice.
+    // samplesInFlight 0 leaves the choice to the renderer: two passes in flight.  The default is one region
+    // and that choice.
     void setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight = 1);
     std::uint32_t samplesInFlight() const;
     // render() calls are collected into passes of up to `samples` consecutive samples (1 to 64) that the GPU
@@ -71,9 +71,10 @@ public:
     // but a pass is as long as its slowest rays however few pixels it covers, and a pass over four samples
     // costs less than four passes (1080p, eight samples per pass: 2.76 -> 2.40 ms per sample; an eighth of the
     // frame, as one of eight GPUs renders it: 0.58 -> 0.35 ms).  0, the default, takes the most of 64, 32, 16, 8, 4, 2, 1 samples for which
-    // the wavefront state (332 bytes x pixels covered x samples per pass x passes in flight) stays below
-    // 24 GiB (1 with the final profile, whose photon passes cut the sequence every four samples).  A pass goes
-    // out when it is full, before a photon pass, with a render() call that names a
+    // the wavefront state (rt_wavefront_state_bytes: 356 bytes x pixels covered x samples per pass x passes in
+    // flight) stays below the lesser of 24 GiB and half of the device memory that is free; with a photon map a
+    // pass holds at most eight groups of four samples, each group gathering from the map that was current for
+    // it.  A pass goes out when it is full, with a render() call that names a
     // target of the caller, and whenever the image, the counters or the GPU are asked for (pixels(),
     // linearPixels(), copyOutput(), accumulationBuffer(), outputBuffer(), statistics(), stageTimings(),
     // synchronize()).  Restarts the accumulation.
