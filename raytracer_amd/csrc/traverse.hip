@@ -18,7 +18,6 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
                                                            uint32_t* cursors) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
-    __shared__ LeafShare leafShare[kTraceBlock / 64];
 
     uint32_t spillRef[kPrivateStack];
     float spillT[kPrivateStack];
@@ -27,7 +26,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     RayFeed feed(cursors, n);
     unsigned long long rays = 0;
     tracePersistent<COUNT>(
-        walk, feed, leafShare[threadIdx.x >> 6],
+        walk, feed,
         [&](uint32_t ray) { return RayIn{originTmin[ray], directionTmax[ray], make_uint2(kNoHit, kNoHit)}; },
         [&](uint32_t, const RayIn& in, Traversal<COUNT>& w) {
             const float4 o4 = in.origin, d4 = in.direction;

@@ -49,15 +49,6 @@ namespace rt {
 #ifndef RT_TRACE_POP_AFTER_LEAF
 #define RT_TRACE_POP_AFTER_LEAF 1
 #endif
-// Whether the triangles of the leaves a wave's lanes have reached are tested by all 64 lanes together
-// (one triangle per lane) instead of by the few lanes that own the leaves, one triangle after the other.
-// Off: measured on MI355X the shared phase is slower (3.75 against 3.49 ms per 1080p step even at four
-// waves per SIMD where it does not spill; at five waves it spills 40 registers): publishing the rays,
-// dealing out the triangles and collecting the results through LDS costs every lane of the wave more
-// instructions and two more LDS round trips per turn than the few owners' own tests cost.
-#ifndef RT_TRACE_SHARED_LEAVES
-#define RT_TRACE_SHARED_LEAVES 0
-#endif
 // Whether a refill rides along a turn (the atomic that draws ray indices travels during the node
 // step, the ray loads during the stack and leaf steps) instead of stalling the wave twice.
 #ifndef RT_TRACE_RIDING_REFILL
@@ -66,15 +57,6 @@ namespace rt {
 #ifndef RT_TRACE_GRID_SCALE
 #define RT_TRACE_GRID_SCALE 1
 #endif
-// Whether the walk keeps the children of a node as one group - the node index its inner children start at plus
-// a byte of hit bits - instead of one stack entry per child with its entry distance: a node step then leaves at
-// most one entry behind, nothing is sorted, and the children are taken in the order the ray's direction octant
-// gives (Ylitie, Karras, Laine 2017); the price is that a child that has fallen behind the closest hit is only
-// found out when its node is read.  The leaf children that were hit are tested before the walk goes deeper.
-#ifndef RT_TRACE_GROUPS
-#define RT_TRACE_GROUPS 0
-#endif
-
 #ifndef RT_TRACE_BLOCK
 #define RT_TRACE_BLOCK 256
 #endif
@@ -281,12 +263,6 @@ struct Traversal {
     uint32_t bestPrim, bestInst;
     int sp;
     uint32_t node;
-    // RT_TRACE_GROUPS: the node group the walk is taking children from (index of the first inner child of the
-    // node; bits 0-7 the inner children still to visit, in visiting order, bits 8-15 the node's inner mask), and
-    // the leaf group it is testing (index of the node's first item; bits 0-7 leaf slots still to do, 8-15 the
-    // node's leaf slots, 16-23 those of two items, bit 24: the first item of the slot in turn is done)
-    uint32_t groupBase, groupBits, leafBase, leafBits;
-    static constexpr uint32_t kLeafGroup = 0x80000000U;  // marks a leaf group on the stack
     // overflow stack: arrays owned by the kernel (kept out of this struct so that
     // the rest of the state is promoted to registers)
     uint32_t (&privateRef)[kPrivateStack];
@@ -322,8 +298,7 @@ struct Traversal {
         : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, idx(0.0f),
           idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), found(false),
           anyHit(false), floor(-1), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
-          bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), groupBase(0), groupBits(0), leafBase(0), leafBits(0),
-          privateRef(spillRef), privateT(spillT),
+          bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
           topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
 
     __device__ __forceinline__ void begin(const Ray& ray, float rayTmin, float rayTmax, uint32_t initInstance,
@@ -352,10 +327,6 @@ struct Traversal {
         bestInst = initInstance;
         sp = 0;
         node = 0;  // the top-level root
-        groupBase = 0;  // as a group: one child, the root itself (no inner bits below it, so its index is the base)
-        groupBits = 1;
-        leafBase = 0;
-        leafBits = 0;
     }
 
     __device__ __forceinline__ TraceResult result() const {
@@ -559,228 +530,6 @@ struct Traversal {
     }
 
 
-    // ---- RT_TRACE_GROUPS ---------------------------------------------------------------------------------------
-
-    __device__ __forceinline__ uint32_t octant() const {
-        return (idx < 0.0f ? 1U : 0U) | (idy < 0.0f ? 2U : 0U) | (idz < 0.0f ? 4U : 0U);
-    }
-    // bit j of the result is bit j ^ octant of `slots`: the builder puts a child that lies towards +x / +y / +z of
-    // its node's centre into a slot with bit 0 / 1 / 2 set, so that for a ray that travels towards -x (octant bit
-    // 0) the children come nearest first when slots are taken in ascending slot ^ octant
-    static __device__ __forceinline__ uint32_t inVisitingOrder(uint32_t slots, uint32_t oct) {
-        if (oct & 1U)
-            slots = ((slots & 0xaaU) >> 1) | ((slots & 0x55U) << 1);
-        if (oct & 2U)
-            slots = ((slots & 0xccU) >> 2) | ((slots & 0x33U) << 2);
-        if (oct & 4U)
-            slots = ((slots & 0xf0U) >> 4) | ((slots & 0x0fU) << 4);
-        return slots;
-    }
-    // bit `bit` of each of the eight bytes of lo : hi as an 8-bit mask
-    static __device__ __forceinline__ uint32_t byteBits(uint32_t lo, uint32_t hi, int bit) {
-        const uint32_t a = ((lo >> bit) & 0x01010101U) * 0x01020408U >> 24;
-        const uint32_t b = ((hi >> bit) & 0x01010101U) * 0x01020408U >> 24;
-        return (a & 15U) | (b & 15U) << 4;
-    }
-    __device__ __forceinline__ void pushGroup(uint32_t base, uint32_t bits) {
-        if (sp < kLdsStack) {
-            stackRef[sp * stride] = base;
-            ((LdsUint)stackT)[sp * stride] = bits;
-        } else if (sp < kMaxStack) {
-            privateRef[sp - kLdsStack] = base;
-            privateT[sp - kLdsStack] = __uint_as_float(bits);
-        }
-        ++sp;
-    }
-    __device__ __forceinline__ void leaveInstance() {
-        cur = world;
-        idx = __builtin_amdgcn_rcpf(cur.dx);
-        idy = __builtin_amdgcn_rcpf(cur.dy);
-        idz = __builtin_amdgcn_rcpf(cur.dz);
-        nodes = topNodes;
-        nodeLimit = topNodeLimit;
-        itemLimit = instanceLimit;
-        floor = -1;
-    }
-
-    // The node part of a turn: a lane whose leaf group is empty takes the next child of its node group (the
-    // stack's top group when its own is used up) and does that child's node step.
-    __device__ __forceinline__ void groupNodePhase() {
-        if (node == kDone || (leafBits & 0xffU))
-            return;
-        if (!(groupBits & 0xffU)) {
-            RT_SITE(2);
-            if (sp == 0) {
-                node = kDone;
-                return;
-            }
-            --sp;
-            if (sp < floor)
-                leaveInstance();
-            if (sp >= kMaxStack)
-                return;  // never pushed (guarded against on the host as well)
-            uint32_t base, bits;
-            if (sp < kLdsStack) {
-                base = stackRef[sp * stride];
-                bits = ((LdsUint)stackT)[sp * stride];
-            } else {
-                base = privateRef[sp - kLdsStack];
-                bits = __float_as_uint(privateT[sp - kLdsStack]);
-            }
-            if (bits & kLeafGroup) {
-                leafBase = base;
-                leafBits = bits & ~kLeafGroup;
-                return;
-            }
-            groupBase = base;
-            groupBits = bits;
-        }
-        const uint32_t oct = octant();
-        const uint32_t turn = static_cast<uint32_t>(__ffs(static_cast<int>(groupBits & 0xffU)) - 1);
-        const uint32_t slot = turn ^ oct;
-        groupBits &= ~(1U << turn);
-        const uint32_t inner = (groupBits >> 8) & 0xffU;
-        groupNodeStep(groupBase + __popc(inner & ((1U << slot) - 1U)), oct);
-    }
-
-    __device__ __forceinline__ void groupNodeStep(uint32_t index, uint32_t oct) {
-        RT_SITE(0);
-        RT_GUARD(index < nodeLimit);
-        if (COUNT)
-            ++counters.nodes;
-        GlobalUint4 np = globalView(nodes + index);
-        const uint4 n0 = np[0];
-        uint4 n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        uint32_t imask = n0.w >> 24;
-        if ((cur.dx * cur.dy) * cur.dz == 0.0f) {  // a ray parallel to an axis: see nodeStep
-            auto outsideSlab = [&](float direction, float origin, uint32_t corner, uint32_t exponent, uint32_t lo0,
-                                   uint32_t lo1, uint32_t hi0, uint32_t hi1) -> uint32_t {
-                if (direction != 0.0f)
-                    return 0U;
-                const float scale = __uint_as_float((exponent & 0xffU) << 23);
-                const float offset = __uint_as_float(corner) - origin;
-                const float margin = 0x1p-20f * ((fabsf(__uint_as_float(corner)) + fabsf(origin)) + 255.0f * scale);
-                uint32_t outside = 0U;
-#pragma unroll
-                for (int i = 0; i < kWide; ++i) {
-                    const int sh = 8 * (i & 3);
-                    const float qlo = static_cast<float>(((i < 4 ? lo0 : lo1) >> sh) & 0xffU);
-                    const float qhi = static_cast<float>(((i < 4 ? hi0 : hi1) >> sh) & 0xffU);
-                    if (fmaf(qlo, scale, offset) > margin || fmaf(qhi, scale, offset) < -margin)
-                        outside |= 1U << i;
-                }
-                return outside;
-            };
-            const uint32_t outside = outsideSlab(cur.dx, cur.ox, n0.x, n0.w, n2.x, n2.y, n3.z, n3.w) |
-                                     outsideSlab(cur.dy, cur.oy, n0.y, n0.w >> 8, n2.z, n2.w, n4.x, n4.y) |
-                                     outsideSlab(cur.dz, cur.oz, n0.z, n0.w >> 16, n3.x, n3.y, n4.z, n4.w);
-            auto bytesOf = [](uint32_t four) -> uint32_t {
-                return ((four & 1U) ? 0xffU : 0U) | ((four & 2U) ? 0xff00U : 0U) | ((four & 4U) ? 0xff0000U : 0U) |
-                       ((four & 8U) ? 0xff000000U : 0U);
-            };
-            const uint32_t b0 = bytesOf(outside & 15U), b1 = bytesOf(outside >> 4);
-            n2.x |= b0; n2.y |= b1; n2.z |= b0; n2.w |= b1; n3.x |= b0; n3.y |= b1;
-            n3.z &= ~b0; n3.w &= ~b1; n4.x &= ~b0; n4.y &= ~b1; n4.z &= ~b0; n4.w &= ~b1;
-        }
-        const float ax = __uint_as_float((n0.w & 0xffU) << 23) * idx;
-        const float ay = __uint_as_float(((n0.w >> 8) & 0xffU) << 23) * idy;
-        const float az = __uint_as_float(((n0.w >> 16) & 0xffU) << 23) * idz;
-        const float bx = (__uint_as_float(n0.x) - cur.ox) * idx;
-        const float by = (__uint_as_float(n0.y) - cur.oy) * idy;
-        const float bz = (__uint_as_float(n0.z) - cur.oz) * idz;
-        const float axn = ax * kShrink, ayn = ay * kShrink, azn = az * kShrink;
-        const float bxn = bx * kShrink, byn = by * kShrink, bzn = bz * kShrink;
-        const float axf = ax * kGrow, ayf = ay * kGrow, azf = az * kGrow;
-        const float bxf = bx * kGrow, byf = by * kGrow, bzf = bz * kGrow;
-        const float limit = bestT * kGrow;
-        const bool nx = idx < 0.0f, ny = idy < 0.0f, nz = idz < 0.0f;
-        const uint32_t xlo0 = nx ? n3.z : n2.x, xlo1 = nx ? n3.w : n2.y;
-        const uint32_t xhi0 = nx ? n2.x : n3.z, xhi1 = nx ? n2.y : n3.w;
-        const uint32_t ylo0 = ny ? n4.x : n2.z, ylo1 = ny ? n4.y : n2.w;
-        const uint32_t yhi0 = ny ? n2.z : n4.x, yhi1 = ny ? n2.w : n4.y;
-        const uint32_t zlo0 = nz ? n4.z : n3.x, zlo1 = nz ? n4.w : n3.y;
-        const uint32_t zhi0 = nz ? n3.x : n4.z, zhi1 = nz ? n3.y : n4.w;
-        uint32_t hitMask = 0;
-#pragma unroll
-        for (int i = 0; i < kWide; ++i) {
-            const int sh = 8 * (i & 3);
-            const float qxn = static_cast<float>(((i < 4 ? xlo0 : xlo1) >> sh) & 0xffU);
-            const float qxf = static_cast<float>(((i < 4 ? xhi0 : xhi1) >> sh) & 0xffU);
-            const float qyn = static_cast<float>(((i < 4 ? ylo0 : ylo1) >> sh) & 0xffU);
-            const float qyf = static_cast<float>(((i < 4 ? yhi0 : yhi1) >> sh) & 0xffU);
-            const float qzn = static_cast<float>(((i < 4 ? zlo0 : zlo1) >> sh) & 0xffU);
-            const float qzf = static_cast<float>(((i < 4 ? zhi0 : zhi1) >> sh) & 0xffU);
-            const float tn = fmaxf(fmaxf(fmaf(qxn, axn, bxn), fmaf(qyn, ayn, byn)), fmaxf(fmaf(qzn, azn, bzn), tminShrunk));
-            const float tf = fminf(fminf(fmaf(qxf, axf, bxf), fmaf(qyf, ayf, byf)), fminf(fmaf(qzf, azf, bzf), limit));
-            hitMask |= tn <= tf ? (1U << i) : 0U;
-        }
-        // leaf slots: the item count of a meta byte sits in its bits 5-7 (one item: bit 5, two: bit 6); the bytes of
-        // inner and empty slots have none of them
-        static_assert(kMaxLeaf <= 2 || !RT_TRACE_GROUPS, "the leaf group keeps one bit per slot for a second item");
-        const uint32_t two = byteBits(n1.z, n1.w, 6);
-        const uint32_t leaves = (byteBits(n1.z, n1.w, 5) | two) & ~imask;
-        // the group this node's inner children are taken from replaces the one in hand, which waits on the stack
-        // when it has children left
-        if (groupBits & 0xffU)
-            pushGroup(groupBase, groupBits);
-        groupBase = n1.x;
-        groupBits = inVisitingOrder(hitMask & imask, oct) | imask << 8;
-        leafBase = n1.y;
-        leafBits = (hitMask & leaves) | leaves << 8 | two << 16;
-    }
-
-    // The leaf part of a turn: one item of the leaf group - a triangle, or in the top level an instance to enter.
-    __device__ __forceinline__ void groupLeafPhase() {
-        if (node == kDone || !(leafBits & 0xffU))
-            return;
-        const uint32_t slot = static_cast<uint32_t>(__ffs(static_cast<int>(leafBits & 0xffU)) - 1);
-        const uint32_t before = (1U << slot) - 1U;
-        const uint32_t leaves = (leafBits >> 8) & 0xffU, two = (leafBits >> 16) & 0xffU, second = (leafBits >> 24) & 1U;
-        const uint32_t item = leafBase + __popc(leaves & before) + __popc(two & before) + second;
-        if (!inBottom()) {
-            leafBits &= ~(1U << slot);
-            // what is left of this top-level node waits below the instance: its other instances, its inner children
-            if (leafBits & 0xffU)
-                pushGroup(leafBase, leafBits | kLeafGroup);
-            if (groupBits & 0xffU)
-                pushGroup(groupBase, groupBits);
-            leafBits = 0;
-            node = kLeafBit | item;
-            enterInstance();
-            if (node == kDone)
-                return;
-            groupBase = 0;  // the instance's root, as a group of one
-            groupBits = 1;
-            return;
-        }
-        RT_SITE(3);
-        if (COUNT)
-            ++counters.triangles;
-        RT_GUARD(item < itemLimit);
-        GlobalUint4 tp = globalView(triangles + item);
-        const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-        float t, u, v;
-        if (intersectTriangle(cur, shear, p0, p1, p2, tmin, bestT, t, u, v)) {
-            const uint32_t prim = p0.w;
-            if (t < bestT || instanceId < bestInst || (instanceId == bestInst && prim < bestPrim)) {
-                bestT = t;
-                bestU = u;
-                bestV = v;
-                bestPrim = prim;
-                bestInst = instanceId;
-                found = true;
-            }
-        }
-        if (anyHit && found) {
-            node = kDone;
-            return;
-        }
-        if (((two >> slot) & 1U) && !second)
-            leafBits |= 1U << 24;
-        else
-            leafBits &= ~((1U << 24) | (1U << slot));
-    }
-
     // Top-level leaf: move the ray into the instance's object space.
     __device__ __forceinline__ void enterInstance() {
         RT_SITE(4);
@@ -810,45 +559,6 @@ struct Traversal {
         nodeLimit = q4.z;
         itemLimit = q4.w;
         node = 0;
-    }
-
-    // Shared leaf phase, owner side: whether this lane stands at a bottom-level leaf whose triangles
-    // are all inside the triangle array (a leaf that is not ends the ray, as triangleStep would).
-    __device__ __forceinline__ bool atTriangles() {
-        if (!((node & kLeafBit) && node < kPop && inBottom()))
-            return false;
-        const uint32_t count = (node >> 28) & 7U, first = node & 0x0fffffffU;
-        if (first + count > itemLimit || count == 0U) {
-            ++violations;
-            found = false;
-            node = kDone;
-            return false;
-        }
-        return true;
-    }
-    // What a lane that tests one of this lane's triangles needs to know.
-    __device__ __forceinline__ void publish(uint4 (&record)[3]) const {
-        const uintptr_t base = reinterpret_cast<uintptr_t>(triangles);
-        record[0] = make_uint4(__float_as_uint(cur.ox), __float_as_uint(cur.oy), __float_as_uint(cur.oz), __float_as_uint(tmin));
-        record[1] = make_uint4(__float_as_uint(shear.Sx), __float_as_uint(shear.Sy), __float_as_uint(shear.Sz),
-                               __float_as_uint(bestT));
-        record[2] = make_uint4(static_cast<uint32_t>(shear.kx | shear.ky << 2 | shear.kz << 4), static_cast<uint32_t>(base),
-                               static_cast<uint32_t>(base >> 32), node & 0x0fffffffU);
-    }
-    // One tested triangle comes back: the closest hit is the least (t, instance, primitive), whatever
-    // order the triangles are taken in.
-    __device__ __forceinline__ void accept(const uint4& r) {
-        if (r.w == kNoHit)
-            return;
-        const float t = __uint_as_float(r.x);
-        if (t < bestT || (t == bestT && (instanceId < bestInst || (instanceId == bestInst && r.w < bestPrim)))) {
-            bestT = t;
-            bestU = __uint_as_float(r.y);
-            bestV = __uint_as_float(r.z);
-            bestPrim = r.w;
-            bestInst = instanceId;
-            found = true;
-        }
     }
 
     // Bottom-level leaf: tests its next triangle.  The leaf reference counts down;
@@ -882,15 +592,6 @@ struct Traversal {
         else
             node = kPop;
     }
-};
-
-// Scratch of one wave for the shared leaf phase (tracePersistent): the rays of up to kShareOwners lanes
-// whose walk stands at a leaf, which (owner, triangle) each of the 64 lanes tests, and what it found.
-constexpr int kShareOwners = 16;
-struct LeafShare {
-    uint4 ray[kShareOwners][3];  // (origin, tmin), (Sx, Sy, Sz, tmax), (kx | ky << 2 | kz << 4, triangles lo, hi, first)
-    uint4 found[64];             // t, u, v, primitive (kNoHit: no hit)
-    uint32_t item[64];           // owner slot << 2 | triangle of the leaf
 };
 
 // Hands out ray indices [0, n) to the waves of a persistent launch.  The range
@@ -971,38 +672,6 @@ struct RayFeed {
     }
 };
 
-// Shared leaf phase, tester side: the triangle `item` names, against the ray its owner published.
-__device__ __forceinline__ uint4 testShared(const LeafShare& share, uint32_t item) {
-    const uint4 r0 = share.ray[item >> 2][0], r1 = share.ray[item >> 2][1], r2 = share.ray[item >> 2][2];
-    Ray ray;
-    ray.ox = __uint_as_float(r0.x);
-    ray.oy = __uint_as_float(r0.y);
-    ray.oz = __uint_as_float(r0.z);
-    ray.dx = ray.dy = ray.dz = 0.0f;  // the test works from the sheared ray
-    Shear shear;
-    shear.kx = static_cast<int>(r2.x & 3U);
-    shear.ky = static_cast<int>((r2.x >> 2) & 3U);
-    shear.kz = static_cast<int>((r2.x >> 4) & 3U);
-    shear.Sx = __uint_as_float(r1.x);
-    shear.Sy = __uint_as_float(r1.y);
-    shear.Sz = __uint_as_float(r1.z);
-    const PackedTriangle* triangles =
-        reinterpret_cast<const PackedTriangle*>(static_cast<uintptr_t>(r2.y) | static_cast<uintptr_t>(r2.z) << 32);
-    GlobalUint4 tp = globalView(triangles + (r2.w + (item & 3U)));
-    const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-    float t, u, v;
-    if (!intersectTriangle(ray, shear, p0, p1, p2, __uint_as_float(r0.w), __uint_as_float(r1.w), t, u, v))
-        return make_uint4(0U, 0U, 0U, kNoHit);
-    return make_uint4(__float_as_uint(t), __float_as_uint(u), __float_as_uint(v), p0.w);
-}
-
-// Orders the LDS traffic of one wave: what lanes wrote before it, other lanes of the wave read after it.
-__device__ __forceinline__ void waveSync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // A ray as it comes out of memory, before a lane's walk takes it over.
 struct RayIn {
     float4 origin, direction;  // (origin, tmin), (direction, tmax)
@@ -1017,7 +686,7 @@ struct RayIn {
 // and one leaf (up to RT_TRACE_LEAF_STEPS triangles of it), so the lanes of a
 // wave run the node code together and the leaf code together.
 template <bool COUNT, typename Load, typename Start, typename Store>
-__device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, LeafShare& share, Load&& load,
+__device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed& feed, Load&& load,
                                                 Start&& start, Store&& store) {
     bool active = false;
     uint32_t rayIndex = 0;
@@ -1074,9 +743,6 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             uint32_t raySteps = 0;
             RT_SITE(5);
 #endif
-#if RT_TRACE_GROUPS
-            walk.groupNodePhase();
-#else
             // A turn is flat: one wide node for the lanes at one, then one stack entry
             // for the lanes that ran out of work (kPop), then the leaf code.  A loop
             // at any of these places makes the other lanes of the wave wait for its
@@ -1084,7 +750,6 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             // (three nodes per turn spilt 26-48 registers; this form spills none).
             if (!(walk.node & kLeafBit))
                 walk.nodeStep();
-#endif
 #if RT_TRACE_RIDING_REFILL
         }
         bool taking = false;
@@ -1097,9 +762,6 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
         }
         if (active) {
 #endif
-#if RT_TRACE_GROUPS
-            walk.groupLeafPhase();
-#else
             if (walk.node == kPop)
                 walk.node = walk.pop();
             if ((walk.node & 0xf0000000U) == kLeafBit)
@@ -1108,65 +770,19 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
                 if (!walk.inBottom()) {
                     walk.enterInstance();
                 }
-#if !RT_TRACE_SHARED_LEAVES
                 else {
                     const uint32_t count = min((walk.node >> 28) & 7U, static_cast<uint32_t>(RT_TRACE_LEAF_STEPS));
                     for (uint32_t k = 0; k < count && walk.node < kPop; ++k)
                         walk.triangleStep();
                 }
-#endif
             }
-#if RT_TRACE_POP_AFTER_LEAF && !RT_TRACE_SHARED_LEAVES
+#if RT_TRACE_POP_AFTER_LEAF
             // a lane whose leaf is done takes its next stack entry at once, so that it starts the
             // next turn at a node instead of spending that turn's node step idle
             if (walk.node == kPop)
                 walk.node = walk.pop();
 #endif
-#endif
         }
-#if RT_TRACE_SHARED_LEAVES
-        // The leaf phase is the wave's, not the lane's: the lanes that stand at a leaf (typically a
-        // handful, each with one to four triangles) publish their rays, the triangles are dealt out
-        // one per lane over all 64 lanes, idle ones included, tested in one go, and the owners take
-        // the results back in triangle order.  A leaf is finished in the turn it is reached.
-        {
-            const int lane = threadIdx.x & 63;
-            const unsigned long long below = (1ULL << lane) - 1ULL;
-            bool wants = active && walk.atTriangles();
-            unsigned long long waiting = __ballot(wants);
-            while (waiting) {
-                const uint32_t slot = __popcll(waiting & below);
-                const bool owner = wants && slot < static_cast<uint32_t>(kShareOwners);
-                const uint32_t count = owner ? (walk.node >> 28) & 7U : 0U;
-                // triangles before this lane's: counts are at most 4, three ballots carry them
-                const unsigned long long c0 = __ballot(count & 1U), c1 = __ballot(count & 2U), c2 = __ballot(count & 4U);
-                const uint32_t before = __popcll(c0 & below) + 2U * __popcll(c1 & below) + 4U * __popcll(c2 & below);
-                const uint32_t total = __popcll(c0) + 2U * __popcll(c1) + 4U * __popcll(c2);
-                if (owner) {
-                    walk.publish(share.ray[slot]);
-                    for (uint32_t k = 0; k < count; ++k)
-                        share.item[before + k] = slot << 2 | k;
-                    if (COUNT)
-                        walk.counters.triangles += count;
-                }
-                waveSync();
-                if (static_cast<uint32_t>(lane) < total)
-                    share.found[lane] = testShared(share, share.item[lane]);
-                waveSync();
-                if (owner) {
-                    for (uint32_t k = 0; k < count; ++k)
-                        walk.accept(share.found[before + k]);
-                    walk.node = walk.anyHit && walk.found ? kDone : kPop;
-                    wants = false;
-                }
-                waiting = __ballot(wants);
-            }
-#if RT_TRACE_POP_AFTER_LEAF
-            if (active && walk.node == kPop)
-                walk.node = walk.pop();
-#endif
-        }
-#endif
         if (active && walk.node == kDone) {
             store(rayIndex, walk.result());
             active = false;

@@ -251,7 +251,6 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
                                                            Buffers b, int which, int withShadow, uint2 limits) {
     __shared__ uint32_t stackRef[kLdsStack][kTraceBlock];
     __shared__ float stackT[kLdsStack][kTraceBlock];
-    __shared__ LeafShare leafShare[kTraceBlock / 64];
     uint32_t spillRef[kPrivateStack];
     float spillT[kPrivateStack];
     Traversal<COUNT> walk(topNodes, limits.x, instances, limits.y, ldsView(&stackRef[0][threadIdx.x]),
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(kTraceBlock, RT_TRACE_MIN_WAVES) void traceKernel(c
     const float4* origins = b.rayOrigin[which >= 0 ? which : 0];
     const float4* directions = b.rayDirection[which >= 0 ? which : 0];
     tracePersistent<COUNT>(
-        walk, feed, leafShare[threadIdx.x >> 6],
+        walk, feed,
         [&](uint32_t index) {
             if (index < extendCount)
                 return RayIn{origins[index], directions[index], make_uint2(kNoHit, kNoHit)};

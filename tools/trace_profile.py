@@ -5,6 +5,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("RT_BENCH_ROOT"):  # a side-by-side build of the package (tools/variants.sh)
+    sys.path.insert(0, os.path.abspath(os.environ["RT_BENCH_ROOT"]))
 import torch  # noqa: F401  (initialises the device)
 from raytracer_amd import engine, renderer as R, workloads
 
