@@ -171,6 +171,13 @@ typedef struct rt_instance_desc {
  * dropped stack entries. */
 rt_status rt_scene_build(const rt_instance_desc* instances, uint32_t instanceCount, void* stream, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+/* rt_scene_build puts the triangles of an instance into the tree over the instances themselves when the
+ * instance's transform is the identity bit for bit and its mesh has at most 64 triangles (at most 4096 such
+ * triangles per scene): a ray then tests them where it would have entered the instance.  The intersection
+ * arithmetic and every reported hit (t, u, v, primitive, instance) are those of the instance; RT_SCENE_FOLD=0
+ * in the environment folds nothing.  No counterpart in the reference (OptiX decides such things inside its
+ * acceleration-structure build).  Reports how many instances and triangles of `scene` were folded. */
+rt_status rt_scene_folded(const rt_scene* scene, uint32_t* instances, uint32_t* triangles);
 /* The hit-group records of the shader binding table (src/renderer.cpp:649-660):
  * one rt_hit_group_data per geometry, indexed by rt_instance_desc.geometry.
  * `records` is host memory holding device pointers; the shading kernels read
@@ -217,7 +224,8 @@ typedef struct rt_ray_hit {
  *
  * n rays as two device arrays of float4: (origin, tmin) and (direction, tmax).
  * A hit has tmin < t <= tmax; the closest hit is the smallest t, exact ties
- * going to the lowest (instance, primitive).  instance[i] = instanceId or
+ * going to the lowest (instance, primitive).  A tmin below zero or NaN counts
+ * as zero (the reference's traversal rejects such a ray as invalid).  instance[i] = instanceId or
  * 0xffffffff. */
 rt_status rt_trace_closest(const rt_scene* scene, const rt_float4* originTmin, const rt_float4* directionTmax,
                            uint32_t n, rt_ray_hit* hits, uint32_t* instance, void* stream);

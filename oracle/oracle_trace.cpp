@@ -412,7 +412,9 @@ void traceInstance(const Scene& scene, uint32_t index, V3 o, V3 d, float tmin, b
 Best traceScene(const Scene& scene, const float* org, const float* dir, bool useBvh, bool any) {
     const V3 o{org[0], org[1], org[2]};
     const V3 d{dir[0], dir[1], dir[2]};
-    const float tmin = org[3];
+    // A ray starts at its origin at the earliest: a tmin below zero (or one that is no number) counts as zero.  The
+    // reference's traversal takes no such ray at all (OptiX reports a negative or NaN tmin as an invalid ray).
+    const float tmin = std::fmax(org[3], 0.0f);
     Best best{dir[3], 0.0f, 0.0f, 0xffffffffU, 0xffffffffU};
     const float invd[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     for (uint32_t i = 0; i < scene.instances.size(); ++i) {

@@ -57,7 +57,15 @@ struct alignas(16) PackedTriangle {
 };
 static_assert(sizeof(PackedTriangle) == 48, "packed triangle is 48 bytes");
 
-// Top-level leaf item: 80 bytes.
+// A top-level leaf item is an instance or a single triangle in world space (a folded triangle): an instance
+// whose transform is the identity, bit for bit, and whose mesh is small costs a ray more to enter - transform,
+// shear constants, the mesh's one or two nodes - than its triangles cost to test, so rt_scene_build puts such
+// triangles into the top-level tree themselves.  The identity transform leaves every coordinate as it is, so the
+// intersection arithmetic and its results are those of the instance.  Both kinds of item are 80-byte records of
+// one array; a folded triangle is a PackedTriangle (pad1 = its instance's id) in the first 48 bytes, and the leaf
+// reference that leads to it carries kFoldedBit.
+constexpr uint32_t kFoldedBit = 0x40000000U;
+
 struct alignas(16) InstanceRecord {
     float toObject[12];           // world->object, row-major 3x4
     const WideNode* nodes;        // bottom-level root
@@ -118,6 +126,8 @@ struct rt_scene {
     rt::InstanceRecord* instances = nullptr;
     uint64_t nodeCount = 0;
     uint32_t instanceCount = 0;
+    uint32_t itemCount = 0;                 // records behind `instances`: instances that are entered + folded triangles
+    uint32_t foldedTriangles = 0, foldedInstances = 0;
     uint32_t depth = 0;
     uint64_t blasNodes = 0, blasNodeBytes = 0, triangles = 0, triangleBytes = 0;
     uint32_t blasDepth = 0;

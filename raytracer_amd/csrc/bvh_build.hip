@@ -638,15 +638,25 @@ __device__ inline float scaleOf(uint8_t e) {
     return __uint_as_float(static_cast<uint32_t>(e) << 23);
 }
 
-// Grows the box by a few ulps of its coordinates: the traversal's slab test
-// then never rejects a triangle its own intersection test accepts.
+// Grows the box by a few ulps of its largest coordinate, on every axis: the traversal's slab test then never
+// rejects a triangle its own intersection test accepts.  The distance that test computes is a weighted sum of
+// the corners' distances along the ray's main axis, so its rounding error is a few ulps of the triangle's size
+// whatever the distance itself, and moves the hit point by as much along every axis; a margin taken from an
+// axis' own coordinates would be nothing on the axis a flat triangle has no extent on (a floor at y = 0), and a
+// query whose interval ends at a hit (tmax = t, or a second triangle at the same distance) could lose it.
+__host__ __device__ inline float boxMargin(const float* lo, const float* hi) {
+    float m = 0.0f;
+    for (int a = 0; a < 3; ++a)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), hi[a] - lo[a]));
+    return fmaxf(m * 0x1p-18f, 1e-30f);
+}
+
 __device__ inline void padBox(Box4& b) {
     float* lo = &b.lo.x;
     float* hi = &b.hi.x;
+    const float pad = boxMargin(lo, hi);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float m = fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), hi[a] - lo[a]);
-        const float pad = fmaxf(m * 0x1p-18f, 1e-30f);
         lo[a] -= pad;
         hi[a] += pad;
     }
@@ -1359,9 +1369,10 @@ float scaleOfHost(uint8_t e) {
 // to eight children by repeatedly splitting the group with the largest box (see
 // split()); a group of one instance is a leaf child.
 struct TopBuilder {
-    const std::vector<Aabb>& boxes;
-    std::vector<uint32_t> order;      // instance permutation the splits work on
-    std::vector<uint32_t> items;      // instance index per leaf item slot, contiguous per node
+    const std::vector<Aabb>& boxes;   // one per item: an instance, or a folded triangle (see kFoldedBit)
+    const std::vector<uint8_t>& folded;  // per item: whether it is a folded triangle
+    std::vector<uint32_t> order;      // item permutation the splits work on
+    std::vector<uint32_t> items;      // item index per leaf item slot, contiguous per node
     std::vector<WideNode> nodes;
     uint32_t depth = 0;
     // Levels the tree may have: what the traversal stack leaves after the deepest bottom-level tree.  Cuts by
@@ -1377,7 +1388,7 @@ struct TopBuilder {
         Aabb box;
     };
 
-    explicit TopBuilder(const std::vector<Aabb>& b) : boxes(b), order(b.size()) {
+    TopBuilder(const std::vector<Aabb>& b, const std::vector<uint8_t>& f) : boxes(b), folded(f), order(b.size()) {
         for (uint32_t i = 0; i < order.size(); ++i)
             order[i] = i;
     }
@@ -1540,7 +1551,9 @@ struct TopBuilder {
                 pending.emplace_back(childBase + slot, g);
                 ++slot;
             } else {
-                node.meta[k] = static_cast<uint8_t>(1U << 5 | itemSlot);
+                // one item; a folded triangle's count field also carries kFoldedBit's place (bit 2 of the field)
+                const uint32_t field = folded[order[g.first]] ? (kFoldedBit >> 28 | 1U) : 1U;
+                node.meta[k] = static_cast<uint8_t>(field << 5 | itemSlot);
                 items.push_back(order[g.first]);
                 ++itemSlot;
             }
@@ -1556,17 +1569,60 @@ struct TopBuilder {
     }
 };
 
+// Whether an instance's triangles go into the top-level tree themselves (see kFoldedBit): its world->object
+// record is the identity bit for bit and its mesh is small.  RT_SCENE_FOLD=0 folds nothing.
+constexpr uint32_t kFoldTrianglesPerInstance = 64;
+constexpr uint32_t kFoldTrianglesPerScene = 4096;
+
+static bool foldChoice() {
+    const char* v = std::getenv("RT_SCENE_FOLD");
+    return !(v && std::strcmp(v, "0") == 0);
+}
+
+// Bitwise comparison: the zeros of the rotation part must be positive, those of the translation have the sign
+// `translation` names (the inverse of the identity comes out of invertAffine with translations of -0, which the
+// transform of a point adds last and which therefore change no value, not even a zero's sign).
+static bool isIdentity(const float* m, float translation) {
+    const float identity[12] = {1.0f, 0.0f, 0.0f, translation, 0.0f, 1.0f, 0.0f, translation, 0.0f, 0.0f, 1.0f, translation};
+    return std::memcmp(m, identity, sizeof(identity)) == 0;
+}
+
+// Box of one triangle with the margin the bottom-level builder gives its leaf boxes (padBox).
+static Aabb triangleBox(const PackedTriangle& t) {
+    Aabb box = emptyBox();
+    const float* corners[3] = {t.v0, t.v1, t.v2};
+    for (const float* c : corners)
+        for (int a = 0; a < 3; ++a) {
+            box.lo[a] = std::min(box.lo[a], c[a]);
+            box.hi[a] = std::max(box.hi[a], c[a]);
+        }
+    const float pad = boxMargin(box.lo, box.hi);
+    for (int a = 0; a < 3; ++a) {
+        box.lo[a] -= pad;
+        box.hi[a] += pad;
+    }
+    return box;
+}
+
 rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStream_t stream, rt_scene* scene) {
-    std::vector<Aabb> boxes(count);
-    std::vector<InstanceRecord> records(count);
+    // items of the top-level tree: the instances that are entered, and the triangles of those that are folded
+    std::vector<Aabb> boxes;
+    std::vector<uint8_t> folded;
+    std::vector<InstanceRecord> records;
+    boxes.reserve(count);
+    folded.reserve(count);
+    records.reserve(count);
+    std::vector<InstanceRecord> own(count);  // every instance's record, folded or not (the shading table reads it)
     scene->inverses.resize(static_cast<size_t>(count) * 12);
+    const bool fold = foldChoice();
+    std::vector<PackedTriangle> mesh;
     for (uint32_t i = 0; i < count; ++i) {
         const rt_instance_desc& d = instances[i];
         if (!d.blas)
             return failInvalid("instance without a bottom-level structure");
         if (d.blas->device != scene->device)
             return failInvalid("bottom-level structure lives on another device");
-        InstanceRecord& r = records[i];
+        InstanceRecord& r = own[i];
         std::memset(&r, 0, sizeof(r));
         invertAffine(d.transform, r.toObject);
         std::memcpy(&scene->inverses[static_cast<size_t>(i) * 12], r.toObject, sizeof(float) * 12);
@@ -1576,32 +1632,56 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
         r.geometry = d.geometry;
         r.nodeCount = static_cast<uint32_t>(d.blas->nodeCount);
         r.triangleCount = static_cast<uint32_t>(d.blas->triangleCount);
-        boxes[i] = instanceBox(d.transform, d.blas->bounds);
         scene->blasNodes += d.blas->nodeCount;
         scene->triangles += d.blas->triangleCount;
+        if (fold && d.blas->triangleCount <= kFoldTrianglesPerInstance &&
+            scene->foldedTriangles + d.blas->triangleCount <= kFoldTrianglesPerScene && isIdentity(r.toObject, -0.0f) &&
+            isIdentity(d.transform, 0.0f)) {
+            mesh.resize(d.blas->triangleCount);
+            RT_HIP(hipMemcpy(mesh.data(), d.blas->triangles, sizeof(PackedTriangle) * mesh.size(), hipMemcpyDeviceToHost));
+            for (PackedTriangle t : mesh) {
+                t.pad1 = d.instanceId;
+                t.pad2 = 0;
+                InstanceRecord item;
+                std::memset(&item, 0, sizeof(item));
+                static_assert(sizeof(PackedTriangle) <= sizeof(InstanceRecord), "a folded triangle fits an item record");
+                std::memcpy(&item, &t, sizeof(t));
+                boxes.push_back(triangleBox(t));
+                folded.push_back(1);
+                records.push_back(item);
+            }
+            scene->foldedTriangles += static_cast<uint32_t>(mesh.size());
+            ++scene->foldedInstances;
+            continue;
+        }
+        boxes.push_back(instanceBox(d.transform, d.blas->bounds));
+        folded.push_back(0);
+        records.push_back(r);
         scene->blasDepth = std::max(scene->blasDepth, d.blas->depth);
     }
-    TopBuilder builder(boxes);
+    const uint32_t itemCount = static_cast<uint32_t>(records.size());
+    TopBuilder builder(boxes, folded);
     builder.nodes.resize(1);
     // top + bottom levels the traversal stack can follow (fitsTraversalStack): the top tree takes what the deepest
     // bottom-level tree leaves
     uint32_t levels = 0;
     while (fitsTraversalStack(levels + 1U, scene->blasDepth))
         ++levels;
-    if (levels == 0U || count > TopBuilder::capacityOf(levels)) {
+    if (levels == 0U || itemCount > TopBuilder::capacityOf(levels)) {
         setLastError("tree too deep for the traversal stack: " + std::to_string(count) + " instances over bottom-level trees of " +
                      std::to_string(scene->blasDepth) + " levels");
         return RT_ERROR_OUT_OF_RANGE;
     }
     builder.budget = levels;
-    builder.build(0, {0, count, builder.boxOf(0, count)}, 0);
-    std::vector<InstanceRecord> ordered(count);
-    if (builder.items.size() != count)
+    builder.build(0, {0, itemCount, builder.boxOf(0, itemCount)}, 0);
+    std::vector<InstanceRecord> ordered(itemCount);
+    if (builder.items.size() != itemCount)
         return failInvalid("top-level build lost instances");
-    for (uint32_t k = 0; k < count; ++k)
+    for (uint32_t k = 0; k < itemCount; ++k)
         ordered[k] = records[builder.items[k]];
     scene->nodeCount = builder.nodes.size();
     scene->instanceCount = count;
+    scene->itemCount = itemCount;
     scene->depth = builder.depth;
     if (!fitsTraversalStack(scene->depth, scene->blasDepth)) {
         setLastError("tree too deep for the traversal stack: " + std::to_string(scene->depth) + " top levels + " +
@@ -1609,13 +1689,13 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
         return RT_ERROR_OUT_OF_RANGE;
     }
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->nodes), sizeof(WideNode) * builder.nodes.size()));
-    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * count));
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->instances), sizeof(InstanceRecord) * itemCount));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->feedCursors), sizeof(uint32_t) * kFeedWords * kFeedSlots));
     for (hipEvent_t& event : scene->feedEvents)
         RT_HIP(hipEventCreateWithFlags(&event, hipEventDisableTiming));
     RT_HIP(hipMemcpyAsync(scene->nodes, builder.nodes.data(), sizeof(WideNode) * builder.nodes.size(),
                           hipMemcpyHostToDevice, stream));
-    RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice,
+    RT_HIP(hipMemcpyAsync(scene->instances, ordered.data(), sizeof(InstanceRecord) * itemCount, hipMemcpyHostToDevice,
                           stream));
     // shading-side table indexed by instance id
     uint32_t maxId = 0;
@@ -1627,7 +1707,7 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     std::memset(shade.data(), 0, shade.size() * sizeof(ShadeInstance));
     for (uint32_t i = 0; i < count; ++i) {
         ShadeInstance& si = shade[instances[i].instanceId];
-        std::memcpy(si.toObject, records[i].toObject, sizeof(si.toObject));
+        std::memcpy(si.toObject, own[i].toObject, sizeof(si.toObject));
         std::memcpy(si.toWorld, instances[i].transform, sizeof(si.toWorld));
         si.geometry = instances[i].geometry;
     }
@@ -1770,6 +1850,14 @@ rt_status rt_scene_instance_inverse(const rt_scene* scene, uint32_t index, float
     if (!scene || !out12 || index >= scene->instanceCount)
         return failInvalid("instance index");
     std::memcpy(out12, &scene->inverses[static_cast<size_t>(index) * 12], sizeof(float) * 12);
+    return RT_SUCCESS;
+}
+
+rt_status rt_scene_folded(const rt_scene* scene, uint32_t* instances, uint32_t* triangles) {
+    if (!scene || !instances || !triangles)
+        return failInvalid("null argument");
+    *instances = scene->foldedInstances;
+    *triangles = scene->foldedTriangles;
     return RT_SUCCESS;
 }
 

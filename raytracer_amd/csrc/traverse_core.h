@@ -249,6 +249,10 @@ struct Traversal {
 
     Ray world, cur;
     Shear shear;
+    // shear constants of the ray in the top level (where folded triangles are tested), packed: the walk goes
+    // back to them when it leaves an instance
+    float topSx, topSy, topSz;
+    int topAxes;
     float idx, idy, idz;
     const WideNode* nodes;
     const PackedTriangle* triangles;
@@ -295,18 +299,35 @@ struct Traversal {
     __device__ __forceinline__ Traversal(const WideNode* top, uint32_t topCount, const InstanceRecord* inst,
                                          uint32_t instanceCount, LdsUint refs, LdsFloat ts, int s,
                                          uint32_t (&spillRef)[kPrivateStack], float (&spillT)[kPrivateStack])
-        : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, idx(0.0f),
+        : topNodes(top), instances(inst), stackRef(refs), stackT(ts), stride(s), world{}, cur{}, shear{}, topSx(0.0f), topSy(0.0f), topSz(0.0f), topAxes(0), idx(0.0f),
           idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), found(false),
           anyHit(false), floor(-1), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
           bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
           topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
 
+    // The ray in the top level: the world-space ray through the identity transform, operation by operation as
+    // enterInstance() applies a transform, because that is what a folded triangle's instance would have made of
+    // it (the same values; a negative zero or a component that is not finite come out as they would there).  The
+    // translation such an instance adds last is -0 (rt_scene_build folds no other), which changes nothing.
+    __device__ __forceinline__ void toTopLevel() {
+        cur.ox = (world.ox + 0.0f * world.oy) + 0.0f * world.oz;
+        cur.oy = (0.0f * world.ox + world.oy) + 0.0f * world.oz;
+        cur.oz = (0.0f * world.ox + 0.0f * world.oy) + world.oz;
+        cur.dx = (world.dx + 0.0f * world.dy) + 0.0f * world.dz;
+        cur.dy = (0.0f * world.dx + world.dy) + 0.0f * world.dz;
+        cur.dz = (0.0f * world.dx + 0.0f * world.dy) + world.dz;
+    }
+
     __device__ __forceinline__ void begin(const Ray& ray, float rayTmin, float rayTmax, uint32_t initInstance,
                                           uint32_t initPrimitive, bool stopAtFirstHit) {
         anyHit = stopAtFirstHit;
         world = ray;
-        cur = ray;
-        shear = Shear{};
+        toTopLevel();
+        shear = makeShear(cur);
+        topSx = shear.Sx;
+        topSy = shear.Sy;
+        topSz = shear.Sz;
+        topAxes = shear.kx | shear.ky << 2 | shear.kz << 4;
         idx = __builtin_amdgcn_rcpf(cur.dx);
         idy = __builtin_amdgcn_rcpf(cur.dy);
         idz = __builtin_amdgcn_rcpf(cur.dz);
@@ -317,8 +338,11 @@ struct Traversal {
         instanceId = kNoHit;
         floor = -1;
         found = false;
-        tmin = rayTmin;
-        tminShrunk = rayTmin * kShrink;
+        // a ray starts at its origin at the earliest: a tmin below zero, or one that is no number, counts as zero
+        // (fmaxf drops the NaN).  Distances behind the origin then never decide a box test, whose margins
+        // are factors and would lean the wrong way there.
+        tmin = fmaxf(rayTmin, 0.0f);
+        tminShrunk = tmin * kShrink;
         tmax = rayTmax;
         bestT = rayTmax;
         bestU = 0.0f;
@@ -361,7 +385,13 @@ struct Traversal {
             return kDone;
         --sp;
         if (sp < floor) {
-            cur = world;
+            toTopLevel();
+            shear.Sx = topSx;
+            shear.Sy = topSy;
+            shear.Sz = topSz;
+            shear.kx = topAxes & 3;
+            shear.ky = (topAxes >> 2) & 3;
+            shear.kz = topAxes >> 4;
             idx = __builtin_amdgcn_rcpf(cur.dx);
             idy = __builtin_amdgcn_rcpf(cur.dy);
             idz = __builtin_amdgcn_rcpf(cur.dz);
@@ -567,21 +597,24 @@ struct Traversal {
         RT_SITE(3);
         if (COUNT)
             ++counters.triangles;
-        const uint32_t count = (node >> 28) & 7U;
+        static_assert(kMaxLeaf <= 3, "the third bit of a leaf's count field marks a folded triangle");
+        const uint32_t count = (node >> 28) & 3U;
         const uint32_t first = node & 0x0fffffffU;
         RT_GUARD(first < itemLimit);
-        GlobalUint4 tp = globalView(triangles + first);
+        // in the top level the item is a folded triangle: a record of the instance array, its instance's id in it
+        const bool folded = !inBottom();
+        GlobalUint4 tp = folded ? globalView(instances + first) : globalView(triangles + first);
         const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
         float t, u, v;
         if (intersectTriangle(cur, shear, p0, p1, p2, tmin, bestT, t, u, v)) {
-            const uint32_t prim = p0.w;
+            const uint32_t prim = p0.w, instance = folded ? p1.w : instanceId;
             // intersectTriangle only returns t <= bestT
-            if (t < bestT || instanceId < bestInst || (instanceId == bestInst && prim < bestPrim)) {
+            if (t < bestT || instance < bestInst || (instance == bestInst && prim < bestPrim)) {
                 bestT = t;
                 bestU = u;
                 bestV = v;
                 bestPrim = prim;
-                bestInst = instanceId;
+                bestInst = instance;
                 found = true;
             }
         }
@@ -767,11 +800,11 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
             if ((walk.node & 0xf0000000U) == kLeafBit)
                 walk.node = kPop;  // a leaf of no items: an empty slot that passed the slab test
             if ((walk.node & kLeafBit) && walk.node < kPop) {
-                if (!walk.inBottom()) {
+                if (!walk.inBottom() && !(walk.node & kFoldedBit)) {
                     walk.enterInstance();
                 }
                 else {
-                    const uint32_t count = min((walk.node >> 28) & 7U, static_cast<uint32_t>(RT_TRACE_LEAF_STEPS));
+                    const uint32_t count = min((walk.node >> 28) & 3U, static_cast<uint32_t>(RT_TRACE_LEAF_STEPS));
                     for (uint32_t k = 0; k < count && walk.node < kPop; ++k)
                         walk.triangleStep();
                 }

@@ -61,6 +61,7 @@ SYMBOLS = {
     "rt_scene_instance_inverse": (C.c_int, [_vp, _u32, C.POINTER(C.c_float)]),
     "rt_blas_stats": (C.c_int, [_vp, C.POINTER(RtBvhStats)]),
     "rt_scene_stats": (C.c_int, [_vp, C.POINTER(RtBvhStats)]),
+    "rt_scene_folded": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_trace_closest": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rt_trace_any": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
     "rt_trace_closest_counted": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
@@ -322,6 +323,12 @@ class Scene:
         s = RtBvhStats()
         check(load().rt_scene_stats(self.handle, C.byref(s)))
         return s
+
+    def folded(self):
+        """(instances, triangles) that rt_scene_build put into the tree over the instances themselves."""
+        instances, triangles = C.c_uint32(0), C.c_uint32(0)
+        check(load().rt_scene_folded(self.handle, C.byref(instances), C.byref(triangles)))
+        return instances.value, triangles.value
 
     def instance_inverse(self, index):
         out = (C.c_float * 12)()

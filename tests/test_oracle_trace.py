@@ -42,6 +42,19 @@ def test_interval_is_open_below_closed_above(oracle):
     assert s.trace_any(*ray([2.0, 2.0, 1.0], [0, 0, -1]))[0] == 0
 
 
+def test_a_ray_starts_at_its_origin_at_the_earliest(oracle):
+    """A tmin below zero, or one that is no number, counts as zero: nothing behind the origin is a hit, with the
+    oracle's tree or without (the reference's traversal refuses such a ray altogether)."""
+    s = single_triangle(oracle)
+    for tmin in (-10.0, float("nan"), -0.0):
+        for bvh in (False, True):
+            o, d = ray([0.25, 0.25, 1.0], [0, 0, 1], tmin=tmin)          # the triangle lies behind: t = -1
+            assert s.trace_closest(o, d, use_bvh=bvh)[1][0] == 0xffffffff
+            o, d = ray([0.25, 0.25, 1.0], [0, 0, -1], tmin=tmin)         # and in front: t = 1
+            tuv, prim, _ = s.trace_closest(o, d, use_bvh=bvh)
+            assert prim[0] == 0 and tuv[0, 0] == 1.0
+
+
 def test_shared_edge_is_watertight(oracle):
     # rays aimed exactly at the shared diagonal of a quad must hit one of the two triangles
     s = oracle.Scene()
