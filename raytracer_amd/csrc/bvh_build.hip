@@ -1380,6 +1380,7 @@ struct TopBuilder {
     // so a node whose groups would not fit the levels left below it is cut by count instead: eight even parts
     // per node always fit count <= 8^levels.
     uint32_t budget = 0xffffffffU;
+    bool pairs = true;  // leaf children of two folded triangles (RT_SCENE_FOLD=single: one each)
 
     static uint64_t capacityOf(uint32_t levels) { return levels >= 21U ? ~0ULL : 1ULL << (3U * levels); }
 
@@ -1480,6 +1481,11 @@ struct TopBuilder {
     void build(uint32_t self, const Group& group, uint32_t level) {
         depth = std::max(depth, level + 1);
         std::vector<Group> groups{group};
+        // a group of two folded triangles is a leaf child of two items, as in a bottom-level tree: it takes the
+        // place of a node that would hold nothing else
+        auto isLeaf = [&](const Group& g) {
+            return g.count == 1 || (pairs && g.count == 2 && folded[order[g.first]] && folded[order[g.first + 1]]);
+        };
         const uint32_t below = budget > level + 1U ? budget - level - 1U : 0U;  // levels left for the children
         for (int byCount = 0; byCount < 2 && group.count > 1; ++byCount) {
             groups.assign(1, group);
@@ -1502,7 +1508,7 @@ struct TopBuilder {
             }
             bool fits = true;
             for (const Group& g : groups)
-                fits = fits && (g.count == 1 || g.count <= capacityOf(below));
+                fits = fits && (isLeaf(g) || g.count <= capacityOf(below));
             if (fits)
                 break;
         }
@@ -1522,7 +1528,7 @@ struct TopBuilder {
         }
         uint32_t internal = 0;
         for (const auto& g : groups)
-            internal += g.count > 1;
+            internal += !isLeaf(g);
         const uint32_t childBase = static_cast<uint32_t>(nodes.size());
         nodes.resize(nodes.size() + internal);
         node.childBase = childBase;
@@ -1545,17 +1551,18 @@ struct TopBuilder {
                 node.qlo[a][k] = static_cast<uint8_t>(ql);
                 node.qhi[a][k] = static_cast<uint8_t>(qh);
             }
-            if (g.count > 1) {
+            if (!isLeaf(g)) {
                 node.imask |= static_cast<uint8_t>(1U << k);
                 node.meta[k] = static_cast<uint8_t>(slot);
                 pending.emplace_back(childBase + slot, g);
                 ++slot;
             } else {
-                // one item; a folded triangle's count field also carries kFoldedBit's place (bit 2 of the field)
-                const uint32_t field = folded[order[g.first]] ? (kFoldedBit >> 28 | 1U) : 1U;
+                // the count field of folded triangles also carries kFoldedBit's place (bit 2 of the field)
+                const uint32_t field = folded[order[g.first]] ? (kFoldedBit >> 28 | g.count) : 1U;
                 node.meta[k] = static_cast<uint8_t>(field << 5 | itemSlot);
-                items.push_back(order[g.first]);
-                ++itemSlot;
+                for (uint32_t i = 0; i < g.count; ++i)
+                    items.push_back(order[g.first + i]);
+                itemSlot += g.count;
             }
         }
         for (size_t k = groups.size(); k < static_cast<size_t>(kWide); ++k)  // empty slots: a box no ray enters
@@ -1673,6 +1680,8 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
         return RT_ERROR_OUT_OF_RANGE;
     }
     builder.budget = levels;
+    if (const char* v = std::getenv("RT_SCENE_FOLD"))
+        builder.pairs = std::strcmp(v, "single") != 0;
     builder.build(0, {0, itemCount, builder.boxOf(0, itemCount)}, 0);
     std::vector<InstanceRecord> ordered(itemCount);
     if (builder.items.size() != itemCount)

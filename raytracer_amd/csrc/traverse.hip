@@ -76,7 +76,7 @@ rt_status launchTrace(const rt_scene* scene, const rt_float4* originTmin, const 
     RT_HIP(hipMemsetAsync(cursors, 0, kFeedWords * sizeof(uint32_t), s));
     const uint32_t blocks = std::min<uint32_t>(divUp(n, kTraceBlock), persistentBlocks(scene->device));
     hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(blocks), dim3(kTraceBlock), 0, s, scene->nodes,
-                       static_cast<uint32_t>(scene->nodeCount), scene->instances, scene->itemCount,
+                       static_cast<uint32_t>(scene->nodeCount), scene->instances, itemCountWord(scene),
                        reinterpret_cast<const float4*>(originTmin), reinterpret_cast<const float4*>(directionTmax), n,
                        reinterpret_cast<uint4*>(hits), instance, occluded,
                        reinterpret_cast<unsigned long long*>(counters4), cursors);

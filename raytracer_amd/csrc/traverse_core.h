@@ -275,6 +275,7 @@ struct Traversal {
     uint32_t topNodeLimit, instanceLimit;  // sizes of the top-level arrays
     uint32_t nodeLimit, itemLimit;         // sizes of the node and item arrays of the level the ray is in
     uint32_t violations;
+    bool hasFolded;  // the same for every lane: the top level holds folded triangles, so the walk keeps shear constants for it
 #ifdef RT_TRACE_PROFILE
     float profile[16] = {};
     int profileBase = 0;
@@ -295,7 +296,8 @@ struct Traversal {
     }
 #endif
 
-    // topCount / instanceCount: entries of `top` and `inst`.  Every member starts defined.
+    // topCount / instanceCount: entries of `top` and `inst` (see itemCountWord: the top bit of instanceCount
+    // says whether folded triangles are among them).  Every member starts defined.
     __device__ __forceinline__ Traversal(const WideNode* top, uint32_t topCount, const InstanceRecord* inst,
                                          uint32_t instanceCount, LdsUint refs, LdsFloat ts, int s,
                                          uint32_t (&spillRef)[kPrivateStack], float (&spillT)[kPrivateStack])
@@ -303,7 +305,8 @@ struct Traversal {
           idy(0.0f), idz(0.0f), nodes(top), triangles(nullptr), instanceId(kNoHit), found(false),
           anyHit(false), floor(-1), tmin(0.0f), tminShrunk(0.0f), tmax(0.0f), bestT(0.0f), bestU(0.0f), bestV(0.0f),
           bestPrim(kNoHit), bestInst(kNoHit), sp(0), node(kDone), privateRef(spillRef), privateT(spillT),
-          topNodeLimit(topCount), instanceLimit(instanceCount), nodeLimit(topCount), itemLimit(instanceCount), violations(0) {}
+          topNodeLimit(topCount), instanceLimit(instanceCount & 0x7fffffffU), nodeLimit(topCount),
+          itemLimit(instanceCount & 0x7fffffffU), violations(0), hasFolded((instanceCount >> 31) != 0U) {}
 
     // The ray in the top level: the world-space ray through the identity transform, operation by operation as
     // enterInstance() applies a transform, because that is what a folded triangle's instance would have made of
@@ -322,12 +325,16 @@ struct Traversal {
                                           uint32_t initPrimitive, bool stopAtFirstHit) {
         anyHit = stopAtFirstHit;
         world = ray;
-        toTopLevel();
-        shear = makeShear(cur);
-        topSx = shear.Sx;
-        topSy = shear.Sy;
-        topSz = shear.Sz;
-        topAxes = shear.kx | shear.ky << 2 | shear.kz << 4;
+        cur = ray;
+        shear = Shear{};
+        if (hasFolded) {
+            toTopLevel();
+            shear = makeShear(cur);
+            topSx = shear.Sx;
+            topSy = shear.Sy;
+            topSz = shear.Sz;
+            topAxes = shear.kx | shear.ky << 2 | shear.kz << 4;
+        }
         idx = __builtin_amdgcn_rcpf(cur.dx);
         idy = __builtin_amdgcn_rcpf(cur.dy);
         idz = __builtin_amdgcn_rcpf(cur.dz);
@@ -385,13 +392,16 @@ struct Traversal {
             return kDone;
         --sp;
         if (sp < floor) {
-            toTopLevel();
-            shear.Sx = topSx;
-            shear.Sy = topSy;
-            shear.Sz = topSz;
-            shear.kx = topAxes & 3;
-            shear.ky = (topAxes >> 2) & 3;
-            shear.kz = topAxes >> 4;
+            cur = world;
+            if (hasFolded) {
+                toTopLevel();
+                shear.Sx = topSx;
+                shear.Sy = topSy;
+                shear.Sz = topSz;
+                shear.kx = topAxes & 3;
+                shear.ky = (topAxes >> 2) & 3;
+                shear.kz = topAxes >> 4;
+            }
             idx = __builtin_amdgcn_rcpf(cur.dx);
             idy = __builtin_amdgcn_rcpf(cur.dy);
             idz = __builtin_amdgcn_rcpf(cur.dz);
@@ -621,7 +631,7 @@ struct Traversal {
         if (anyHit && found)
             node = kDone;
         else if (count > 1U)
-            node = kLeafBit | (count - 1U) << 28 | (first + 1U);
+            node = (node & (kLeafBit | kFoldedBit)) | (count - 1U) << 28 | (first + 1U);
         else
             node = kPop;
     }
@@ -839,6 +849,11 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
         atomicAdd(&gTraceClock[4], drainLanes);
     }
 #endif
+}
+
+// The item count of a scene as the ray kernels take it: the top bit says that folded triangles are among the items.
+inline uint32_t itemCountWord(const rt_scene* scene) {
+    return scene->itemCount | (scene->foldedTriangles ? 0x80000000U : 0U);
 }
 
 // Workgroups of a persistent traversal launch that fill `device` once: one per

@@ -1271,7 +1271,7 @@ static Buffers buffersFor(const rt_wavefront* w, const rt_launch_params* params)
 
 // Array sizes the ray stage checks references against: top-level nodes, instances.
 static uint2 limitsOf(const rt_scene* scene) {
-    return make_uint2(static_cast<uint32_t>(scene->nodeCount), scene->itemCount);
+    return make_uint2(static_cast<uint32_t>(scene->nodeCount), itemCountWord(scene));
 }
 
 static rt_status checkLaunch(const rt_wavefront* w, const rt_launch_params* params, const rt_scene*& scene) {
