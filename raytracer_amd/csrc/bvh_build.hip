@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -955,130 +956,166 @@ struct UpperBuilder {
     }
 };
 
-// Rebuilds the tree above the radix tree's subtrees of at most `limit` triangles (section 3c) and
-// renumbers the leaves; `order` comes back pointing at the new triangle order.
-rt_status refineUpperLevels(uint32_t n, hipStream_t stream, DeviceBuffer& left, DeviceBuffer& right, DeviceBuffer& parent,
-                            DeviceBuffer& first, DeviceBuffer& last, DeviceBuffer& bounds, DeviceBuffer& counts,
-                            DeviceBuffer& partials, const uint32_t*& order, uint32_t* spareOrder) {
-    // RT_BLAS_TIMING=1 prints where the time of this step goes (host clock, the stream waited for at each mark)
+// Rebuilds the tree above the radix tree's subtrees of at most `limit` triangles by surface area, in two steps
+// so that the host's share runs beside the GPU: start() cuts the clusters out on the device, brings their boxes
+// to the host and hands them to a thread that builds the new upper tree; the caller meanwhile collapses the
+// radix tree as it is.  finish() waits for the thread and puts the rebuilt tree in place only where it is the
+// cheaper one by the measure it was built for (surface area x triangles over its nodes, summed in a fixed order
+// so that every run decides alike) - the caller then collapses again.  On triangles spread evenly the radix
+// tree's median cuts are the surface-area cuts already: nothing is replaced, and the probe has cost the build
+// its device part only.  RT_BLAS_REFINE=always skips the comparison.
+struct UpperRefinement {
+    uint32_t n;
+    hipStream_t stream;
+    DeviceBuffer &left, &right, &parent, &first, &last, &bounds, &counts, &partials;
+    DeviceBuffer marks, roots, upper, upperIds, clusterRecords, upperCost;
+    std::vector<ClusterRecord> clusters;
+    std::vector<uint32_t> ids;
+    std::vector<float> oldCost;
+    uint32_t clusterCount = 0, upperCount = 0;
+    std::unique_ptr<UpperBuilder> builder;
+    std::thread worker;
+    bool started = false;
+    // RT_BLAS_TIMING=1 prints where the time of the steps goes (host clock, the stream waited for at each mark)
     const bool timing = std::getenv("RT_BLAS_TIMING") != nullptr;
-    auto clock = std::chrono::steady_clock::now();
-    auto mark = [&](const char* what) {
+    std::chrono::steady_clock::time_point clock = std::chrono::steady_clock::now();
+
+    UpperRefinement(uint32_t count, hipStream_t s, DeviceBuffer& l, DeviceBuffer& r, DeviceBuffer& p, DeviceBuffer& f,
+                    DeviceBuffer& la, DeviceBuffer& b, DeviceBuffer& c, DeviceBuffer& scan)
+        : n(count), stream(s), left(l), right(r), parent(p), first(f), last(la), bounds(b), counts(c), partials(scan) {}
+    ~UpperRefinement() {
+        if (worker.joinable())
+            worker.join();
+    }
+
+    void mark(const char* what) {
         if (!timing)
             return;
         (void)hipStreamSynchronize(stream);
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "  refine %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - clock).count());
         clock = now;
-    };
-    // about this many clusters (RT_BLAS_CLUSTERS overrides): the host's share of the build grows with it
-    uint32_t targetClusters = 8192;
-    if (const char* v = std::getenv("RT_BLAS_CLUSTERS"))
-        targetClusters = static_cast<uint32_t>(std::max(2L, std::atol(v)));
-    const uint32_t limit = std::max(4U, n / targetClusters);
-    const unsigned idBlocks = divUp(2ULL * n - 1U, 256), blocks = divUp(n, 256);
-    DeviceBuffer marks, roots, upper, upperIds, clusterRecords, upperNodes, leafPosition, leafBounds;
-    RT_TRY(marks.allocate(sizeof(uint32_t) * (static_cast<size_t>(n) + 1)));
-    RT_TRY(roots.allocate(sizeof(uint32_t) * n));
-    RT_TRY(upper.allocate(sizeof(uint32_t) * n));
-    RT_HIP(hipMemsetAsync(marks.data, 0, sizeof(uint32_t) * (static_cast<size_t>(n) + 1), stream));
-    hipLaunchKernelGGL(clusterMarkKernel, dim3(idBlocks), dim3(256), 0, stream, n, limit, parent.as<uint32_t>(),
-                       first.as<uint32_t>(), last.as<uint32_t>(), marks.as<uint32_t>(), roots.as<uint32_t>(),
-                       upper.as<uint32_t>(), counts.as<uint32_t>());
-    RT_TRY(exclusiveScanU32(marks.as<uint32_t>(), marks.as<uint32_t>(), static_cast<size_t>(n) + 1, partials.as<uint32_t>(),
-                            stream));
-    RT_TRY(exclusiveScanU32(upper.as<uint32_t>(), upper.as<uint32_t>(), n, partials.as<uint32_t>(), stream));
-    uint32_t clusterCount = 0, upperCount = 0;
-    RT_HIP(hipMemcpyAsync(&clusterCount, marks.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    RT_HIP(hipMemcpyAsync(&upperCount, upper.as<uint32_t>() + (n - 1U), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    RT_HIP(hipStreamSynchronize(stream));
-    mark("cluster cut + counts");
-    if (clusterCount < 2U)
-        return RT_SUCCESS;  // the whole tree is one cluster
-    if (upperCount + 1U != clusterCount)
-        return failInvalid("cluster cut is not a tree");
-    RT_TRY(clusterRecords.allocate(sizeof(ClusterRecord) * clusterCount));
-    RT_TRY(upperIds.allocate(sizeof(uint32_t) * upperCount));
-    hipLaunchKernelGGL(clusterGatherKernel, dim3(blocks), dim3(256), 0, stream, n, marks.as<uint32_t>(), marks.as<uint32_t>(),
-                       roots.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(),
-                       clusterRecords.as<ClusterRecord>());
-    hipLaunchKernelGGL(upperIdsKernel, dim3(blocks), dim3(256), 0, stream, n, upper.as<uint32_t>(), upperIds.as<uint32_t>());
-    DeviceBuffer upperCost;
-    RT_TRY(upperCost.allocate(sizeof(float) * upperCount));
-    hipLaunchKernelGGL(upperCostKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperIds.as<uint32_t>(), upperCount,
-                       first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(), upperCost.as<float>());
-    std::vector<ClusterRecord> clusters(clusterCount);
-    std::vector<uint32_t> ids(upperCount);
-    std::vector<float> oldCost(upperCount);
-    RT_HIP(hipMemcpyAsync(oldCost.data(), upperCost.data, sizeof(float) * upperCount, hipMemcpyDeviceToHost, stream));
-    RT_HIP(hipMemcpyAsync(clusters.data(), clusterRecords.data, sizeof(ClusterRecord) * clusterCount, hipMemcpyDeviceToHost,
-                          stream));
-    RT_HIP(hipMemcpyAsync(ids.data(), upperIds.data, sizeof(uint32_t) * upperCount, hipMemcpyDeviceToHost, stream));
-    RT_HIP(hipStreamSynchronize(stream));
-    if (ids.empty() || ids[0] != 0U)
-        return failInvalid("the root is not among the upper nodes");
-    mark("clusters to the host");
+    }
 
-    UpperBuilder builder(clusters);
-    builder.build(0, clusterCount);
-    if (builder.nodes.size() != upperCount)
-        return failInvalid("upper tree has the wrong size");
-    mark("surface-area build (host)");
-    // The rebuilt tree is only put in place where it is the cheaper one by the measure it was built for (surface
-    // area x triangles over its nodes, summed in a fixed order so that every run decides alike): on triangles spread
-    // evenly the radix tree's median cuts are the surface-area cuts already, and renumbering a hundred million
-    // leaves for nothing is a fifth of the build.  RT_BLAS_REFINE=always skips the comparison.
-    {
+    static bool always() {
+        const char* choice = std::getenv("RT_BLAS_REFINE");
+        return choice && std::strcmp(choice, "always") == 0;
+    }
+
+    rt_status start() {
+        clock = std::chrono::steady_clock::now();
+        // about this many clusters (RT_BLAS_CLUSTERS overrides): the host's share of the build grows with it
+        uint32_t targetClusters = 8192;
+        if (const char* v = std::getenv("RT_BLAS_CLUSTERS"))
+            targetClusters = static_cast<uint32_t>(std::max(2L, std::atol(v)));
+        const uint32_t limit = std::max(4U, n / targetClusters);
+        const unsigned idBlocks = divUp(2ULL * n - 1U, 256), blocks = divUp(n, 256);
+        RT_TRY(marks.allocate(sizeof(uint32_t) * (static_cast<size_t>(n) + 1)));
+        RT_TRY(roots.allocate(sizeof(uint32_t) * n));
+        RT_TRY(upper.allocate(sizeof(uint32_t) * n));
+        RT_HIP(hipMemsetAsync(marks.data, 0, sizeof(uint32_t) * (static_cast<size_t>(n) + 1), stream));
+        hipLaunchKernelGGL(clusterMarkKernel, dim3(idBlocks), dim3(256), 0, stream, n, limit, parent.as<uint32_t>(),
+                           first.as<uint32_t>(), last.as<uint32_t>(), marks.as<uint32_t>(), roots.as<uint32_t>(),
+                           upper.as<uint32_t>(), counts.as<uint32_t>());
+        RT_TRY(exclusiveScanU32(marks.as<uint32_t>(), marks.as<uint32_t>(), static_cast<size_t>(n) + 1, partials.as<uint32_t>(),
+                                stream));
+        RT_TRY(exclusiveScanU32(upper.as<uint32_t>(), upper.as<uint32_t>(), n, partials.as<uint32_t>(), stream));
+        RT_HIP(hipMemcpyAsync(&clusterCount, marks.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipMemcpyAsync(&upperCount, upper.as<uint32_t>() + (n - 1U), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+        mark("cluster cut + counts");
+        if (clusterCount < 2U)
+            return RT_SUCCESS;  // the whole tree is one cluster
+        if (upperCount + 1U != clusterCount)
+            return failInvalid("cluster cut is not a tree");
+        RT_TRY(clusterRecords.allocate(sizeof(ClusterRecord) * clusterCount));
+        RT_TRY(upperIds.allocate(sizeof(uint32_t) * upperCount));
+        hipLaunchKernelGGL(clusterGatherKernel, dim3(blocks), dim3(256), 0, stream, n, marks.as<uint32_t>(), marks.as<uint32_t>(),
+                           roots.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(),
+                           clusterRecords.as<ClusterRecord>());
+        hipLaunchKernelGGL(upperIdsKernel, dim3(blocks), dim3(256), 0, stream, n, upper.as<uint32_t>(), upperIds.as<uint32_t>());
+        RT_TRY(upperCost.allocate(sizeof(float) * upperCount));
+        hipLaunchKernelGGL(upperCostKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperIds.as<uint32_t>(), upperCount,
+                           first.as<uint32_t>(), last.as<uint32_t>(), bounds.as<Box4>(), upperCost.as<float>());
+        clusters.resize(clusterCount);
+        ids.resize(upperCount);
+        oldCost.resize(upperCount);
+        RT_HIP(hipMemcpyAsync(oldCost.data(), upperCost.data, sizeof(float) * upperCount, hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipMemcpyAsync(clusters.data(), clusterRecords.data, sizeof(ClusterRecord) * clusterCount, hipMemcpyDeviceToHost,
+                              stream));
+        RT_HIP(hipMemcpyAsync(ids.data(), upperIds.data, sizeof(uint32_t) * upperCount, hipMemcpyDeviceToHost, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+        if (ids.empty() || ids[0] != 0U)
+            return failInvalid("the root is not among the upper nodes");
+        mark("clusters to the host");
+        builder = std::make_unique<UpperBuilder>(clusters);
+        worker = std::thread([this] { builder->build(0, clusterCount); });
+        started = true;
+        return RT_SUCCESS;
+    }
+
+    // `replaced` comes back true when the rebuilt upper tree was put in place; `order` then points at the new
+    // triangle order (in spareOrder).
+    rt_status finish(const uint32_t*& order, uint32_t* spareOrder, bool& replaced) {
+        replaced = false;
+        if (!started)
+            return RT_SUCCESS;
+        clock = std::chrono::steady_clock::now();
+        worker.join();
+        if (builder->nodes.size() != upperCount)
+            return failInvalid("upper tree has the wrong size");
+        mark("waiting for the surface-area build");
         double before = 0.0, after = 0.0;
         for (float c : oldCost)
             before += c;
-        for (const UpperBuilder::Node& node : builder.nodes)
+        for (const UpperBuilder::Node& node : builder->nodes)
             after += static_cast<double>(node.box.area()) * node.triangles;
         if (timing)
             std::fprintf(stderr, "  refine cost of the upper tree: radix %.6g, rebuilt %.6g (%.4f)\n", before, after,
                          before > 0.0 ? after / before : 0.0);
-        const char* choice = std::getenv("RT_BLAS_REFINE");
-        const bool always = choice && std::strcmp(choice, "always") == 0;
-        if (!always && !(after < before * 0.98))
+        if (!always() && !(after < before * 0.98))
             return RT_SUCCESS;
+        auto reference = [&](uint32_t r) {
+            return (r & UpperBuilder::kClusterBit) ? clusters[r & ~UpperBuilder::kClusterBit].node : ids[r];
+        };
+        std::vector<UpperNode> scatter(upperCount);
+        for (uint32_t k = 0; k < upperCount; ++k) {
+            const UpperBuilder::Node& node = builder->nodes[k];
+            UpperNode& out = scatter[k];
+            out.box.lo = make_float4(node.box.lo[0], node.box.lo[1], node.box.lo[2], 0.0f);
+            out.box.hi = make_float4(node.box.hi[0], node.box.hi[1], node.box.hi[2], 0.0f);
+            out.id = ids[k];  // pre-order: node 0, the root, keeps id 0
+            out.left = reference(node.left);
+            out.right = reference(node.right);
+            out.triangles = node.triangles;
+        }
+        const unsigned blocks = divUp(n, 256);
+        DeviceBuffer upperNodes, leafPosition, leafBounds;
+        RT_TRY(upperNodes.allocate(sizeof(UpperNode) * upperCount));
+        RT_HIP(hipMemcpyAsync(upperNodes.data, scatter.data(), sizeof(UpperNode) * upperCount, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(upperScatterKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperNodes.as<UpperNode>(),
+                           upperCount, left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), bounds.as<Box4>(),
+                           counts.as<uint32_t>());
+        // leaves in depth-first order of the new tree
+        RT_TRY(leafPosition.allocate(sizeof(uint32_t) * n));
+        RT_TRY(leafBounds.allocate(sizeof(Box4) * n));
+        hipLaunchKernelGGL(plocLeafOrderKernel, dim3(blocks), dim3(256), 0, stream, n, left.as<uint32_t>(), right.as<uint32_t>(),
+                           parent.as<uint32_t>(), counts.as<uint32_t>(), order, bounds.as<Box4>(), leafPosition.as<uint32_t>(),
+                           spareOrder, leafBounds.as<Box4>());
+        hipLaunchKernelGGL(plocRangeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                           right.as<uint32_t>(), parent.as<uint32_t>(), counts.as<uint32_t>(), first.as<uint32_t>(),
+                           last.as<uint32_t>());
+        hipLaunchKernelGGL(plocChildKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
+                           right.as<uint32_t>(), leafPosition.as<uint32_t>());
+        RT_HIP(hipMemcpyAsync(bounds.as<Box4>() + (n - 1U), leafBounds.data, sizeof(Box4) * n, hipMemcpyDeviceToDevice, stream));
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipStreamSynchronize(stream));  // the scratch buffers of this function go out of scope
+        mark("scatter + leaf order");
+        order = spareOrder;
+        replaced = true;
+        return RT_SUCCESS;
     }
-    auto reference = [&](uint32_t r) {
-        return (r & UpperBuilder::kClusterBit) ? clusters[r & ~UpperBuilder::kClusterBit].node : ids[r];
-    };
-    std::vector<UpperNode> scatter(upperCount);
-    for (uint32_t k = 0; k < upperCount; ++k) {
-        const UpperBuilder::Node& node = builder.nodes[k];
-        UpperNode& out = scatter[k];
-        out.box.lo = make_float4(node.box.lo[0], node.box.lo[1], node.box.lo[2], 0.0f);
-        out.box.hi = make_float4(node.box.hi[0], node.box.hi[1], node.box.hi[2], 0.0f);
-        out.id = ids[k];  // pre-order: node 0, the root, keeps id 0
-        out.left = reference(node.left);
-        out.right = reference(node.right);
-        out.triangles = node.triangles;
-    }
-    RT_TRY(upperNodes.allocate(sizeof(UpperNode) * upperCount));
-    RT_HIP(hipMemcpyAsync(upperNodes.data, scatter.data(), sizeof(UpperNode) * upperCount, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(upperScatterKernel, dim3(divUp(upperCount, 256)), dim3(256), 0, stream, upperNodes.as<UpperNode>(),
-                       upperCount, left.as<uint32_t>(), right.as<uint32_t>(), parent.as<uint32_t>(), bounds.as<Box4>(),
-                       counts.as<uint32_t>());
-    // leaves in depth-first order of the new tree
-    RT_TRY(leafPosition.allocate(sizeof(uint32_t) * n));
-    RT_TRY(leafBounds.allocate(sizeof(Box4) * n));
-    hipLaunchKernelGGL(plocLeafOrderKernel, dim3(blocks), dim3(256), 0, stream, n, left.as<uint32_t>(), right.as<uint32_t>(),
-                       parent.as<uint32_t>(), counts.as<uint32_t>(), order, bounds.as<Box4>(), leafPosition.as<uint32_t>(),
-                       spareOrder, leafBounds.as<Box4>());
-    hipLaunchKernelGGL(plocRangeKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
-                       right.as<uint32_t>(), parent.as<uint32_t>(), counts.as<uint32_t>(), first.as<uint32_t>(),
-                       last.as<uint32_t>());
-    hipLaunchKernelGGL(plocChildKernel, dim3(divUp(n - 1, 256)), dim3(256), 0, stream, n, left.as<uint32_t>(),
-                       right.as<uint32_t>(), leafPosition.as<uint32_t>());
-    RT_HIP(hipMemcpyAsync(bounds.as<Box4>() + (n - 1U), leafBounds.data, sizeof(Box4) * n, hipMemcpyDeviceToDevice, stream));
-    RT_HIP(hipGetLastError());
-    RT_HIP(hipStreamSynchronize(stream));  // the scratch buffers of this function go out of scope
-    mark("scatter + leaf order");
-    order = spareOrder;
-    return RT_SUCCESS;
-}
+};
 
 rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
                     hipStream_t stream, rt_blas* blas, bool allowRefine = true) {
@@ -1152,6 +1189,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
 
     hipLaunchKernelGGL(leafBoundsKernel, dim3(blocks), dim3(256), 0, stream, boxes.as<Box4>(), order, n,
                        bounds.as<Box4>());
+    bool probing = false;
     if (n >= 2 && builderChoice() == Builder::Clustering) {
         DeviceBuffer clustersA, clustersB, nearest, keep, merges, leafPosition, leafBounds;
         RT_TRY(clustersA.allocate(sizeof(uint32_t) * n));
@@ -1239,18 +1277,31 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         }
         if (!finished)
             return failInvalid("bounds pass did not finish");
-        if (allowRefine && refineChoice() && n >= 64U)
-            RT_TRY(refineUpperLevels(n, stream, left, right, parent, first, last, bounds, arrivals, partials, order,
-                                     idx[1 - result]));
+        probing = allowRefine && refineChoice() && n >= 64U;
     }
     RT_HIP(hipGetLastError());
+    // The surface-area rebuild of the upper levels runs beside the collapse of the tree as it is (UpperRefinement);
+    // if the rebuilt levels are taken, the collapse runs again over them.
+    UpperRefinement refinement(n, stream, left, right, parent, first, last, bounds, arrivals, partials);
+    if (probing) {
+        RT_TRY(refinement.start());
+        if (UpperRefinement::always()) {
+            bool replaced = false;
+            RT_TRY(refinement.finish(order, idx[1 - result], replaced));
+            probing = false;
+        }
+    }
 
     // top-down collapse, one level per iteration
+    uint32_t levelNodeBase = 0, depth = 0;
+    auto collapse = [&]() -> rt_status {
     uint32_t* frontier = frontierA.as<uint32_t>();
     uint32_t* nextFrontier = frontierB.as<uint32_t>();
     const uint32_t rootId = 0;  // internal node 0, or leaf 0 when n == 1 (id n-1 = 0)
     RT_HIP(hipMemcpyAsync(frontier, &rootId, sizeof(rootId), hipMemcpyHostToDevice, stream));
-    uint32_t entries = 1, levelNodeBase = 0, triBase = 0, depth = 0;
+    uint32_t entries = 1, triBase = 0;
+    levelNodeBase = 0;
+    depth = 0;
     while (entries > 0) {
         if (static_cast<size_t>(levelNodeBase) + entries > maxNodes)
             return failInvalid("wide-node estimate exceeded");
@@ -1284,6 +1335,15 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     }
     if (triBase != n)
         return failInvalid("collapse lost triangles");
+    return RT_SUCCESS;
+    };
+    RT_TRY(collapse());
+    if (probing) {
+        bool replaced = false;
+        RT_TRY(refinement.finish(order, idx[1 - result], replaced));
+        if (replaced)
+            RT_TRY(collapse());
+    }
 
     blas->nodeCount = levelNodeBase;
     blas->triangleCount = n;
