@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -225,41 +226,58 @@ __global__ __launch_bounds__(256) void leafBoundsKernel(const Box4* boxes, const
 //
 // level 0 lists the parents both of whose children are leaves; counts[k] is the
 // length of list k and is zeroed before the first launch.
-// A slot of `list` for every lane of the wave with `wants` set: one atomic per wave on the list's length instead
-// of one per lane (a hundred million lanes adding to one word queue up behind each other: 18 of the 126 ms of a
-// 100 M triangle build).  The order of a list does not enter the bounds.
+// A slot of `list` for every thread of the workgroup with `wants` set: one atomic per workgroup on the list's
+// length.  Atomics on one word queue up behind each other at some 11 ns apiece - one per lane was 18 of the
+// 126 ms of a 100 M triangle build, one per wave still 1.8 of the 14 ms of a 10 M build - so the kernels below
+// run workgroups of 1024 threads and each asks once per pass.  Every thread of the workgroup must call this
+// (it holds barriers).  The order of a list does not enter the bounds.
+constexpr int kRefitBlock = 1024;
 __device__ inline uint32_t appendSlot(bool wants, uint32_t* length) {
+    __shared__ uint32_t waveCount[kRefitBlock / 64];
+    __shared__ uint32_t blockBase;
     const unsigned long long votes = __ballot(wants);
-    if (votes == 0ULL)
-        return 0U;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == __ffsll(static_cast<long long>(votes)) - 1)
-        base = atomicAdd(length, static_cast<uint32_t>(__popcll(votes)));
-    base = __shfl(base, __ffsll(static_cast<long long>(votes)) - 1, 64);
-    return base + __popcll(votes & ((1ULL << lane) - 1ULL));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    if (lane == 0)
+        waveCount[wave] = static_cast<uint32_t>(__popcll(votes));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < waves; ++w)
+            total += waveCount[w];
+        blockBase = total ? atomicAdd(length, total) : 0U;
+    }
+    __syncthreads();
+    uint32_t before = blockBase;
+    for (int w = 0; w < wave; ++w)
+        before += waveCount[w];
+    const uint32_t slot = before + static_cast<uint32_t>(__popcll(votes & ((1ULL << lane) - 1ULL)));
+    __syncthreads();  // the next call of this workgroup writes the counts again
+    return slot;
 }
 
-__global__ __launch_bounds__(256) void refitLeavesKernel(const uint32_t* parent, uint32_t n, uint32_t* arrivals,
-                                                         uint32_t* list, uint32_t* counts) {
-    const size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    uint32_t node = 0;
+// The start of the bounds pass, one thread per inner node: a leaf's box is there from the beginning, so a node's
+// arrival counter starts at the number of its children that are leaves - a plain store where every leaf used to
+// report with an atomic (ten million of them queue up for 1.8 ms) - and a node of two leaves goes on list 0.
+__global__ __launch_bounds__(kRefitBlock) void refitSeedKernel(const uint32_t* left, const uint32_t* right, uint32_t n,
+                                                       uint32_t* arrivals, uint32_t* list, uint32_t* counts) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool ready = false;
-    if (k < n && n >= 2) {
-        node = parent[(n - 1U) + k];
-        ready = atomicAdd(&arrivals[node], 1U) == 1U;
+    if (i + 1U < n) {
+        const uint32_t leaves = (left[i] >= n - 1U ? 1U : 0U) + (right[i] >= n - 1U ? 1U : 0U);
+        arrivals[i] = leaves;
+        ready = leaves == 2U;
     }
     const uint32_t slot = appendSlot(ready, &counts[0]);
     if (ready)
-        list[slot] = node;
+        list[slot] = static_cast<uint32_t>(i);
 }
 
-__global__ __launch_bounds__(256) void refitLevelKernel(const uint32_t* left, const uint32_t* right,
+__global__ __launch_bounds__(kRefitBlock) void refitLevelKernel(const uint32_t* left, const uint32_t* right,
                                                         const uint32_t* parent, Box4* bounds, uint32_t* arrivals,
                                                         const uint32_t* listIn, uint32_t* listOut, uint32_t* counts,
                                                         uint32_t level) {
     const uint32_t ready = counts[level];
-    // whole waves go round together, so that the wave-wide append sees every lane
+    // whole workgroups go round together: the append holds barriers
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t base = static_cast<size_t>(blockIdx.x) * blockDim.x; base < ready; base += stride) {
         const size_t i = base + threadIdx.x;
@@ -769,8 +787,9 @@ static Builder builderChoice() {
 
 struct DeviceBuffer {
     void* data = nullptr;
+    bool borrowed = false;  // a part of another buffer (allocateTogether): not this one's to free
     ~DeviceBuffer() {
-        if (data)
+        if (data && !borrowed)
             (void)hipFree(data);
     }
     rt_status allocate(size_t bytes) {
@@ -782,6 +801,26 @@ struct DeviceBuffer {
         return static_cast<T*>(data);
     }
 };
+
+// One allocation for several buffers (each part aligned to 256 bytes): a build asks for some twenty scratch
+// arrays, and twenty trips to the allocator are a tenth of a ten-million-triangle build.
+struct BufferPart {
+    DeviceBuffer* buffer;
+    size_t bytes;
+};
+static rt_status allocateTogether(DeviceBuffer& whole, std::initializer_list<BufferPart> parts) {
+    size_t total = 0;
+    for (const BufferPart& part : parts)
+        total += (part.bytes + 255U) & ~static_cast<size_t>(255U);
+    RT_TRY(whole.allocate(total));
+    size_t offset = 0;
+    for (const BufferPart& part : parts) {
+        part.buffer->data = static_cast<uint8_t*>(whole.data) + offset;
+        part.buffer->borrowed = true;
+        offset += (part.bytes + 255U) & ~static_cast<size_t>(255U);
+    }
+    return RT_SUCCESS;
+}
 
 
 // ---- surface-area rebuild of the tree above the clusters (host) ----------------
@@ -1124,35 +1163,47 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_HIP(hipEventCreate(&stop));
     RT_HIP(hipEventRecord(start, stream));
 
+    // RT_BLAS_TIMING=1 prints where the time of a build goes (host clock, the stream waited for at each mark)
+    const bool timing = std::getenv("RT_BLAS_TIMING") != nullptr;
+    auto phaseClock = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!timing)
+            return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  build  %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - phaseClock).count());
+        phaseClock = now;
+    };
     const uint32_t ids = 2U * n - 1U;
     const size_t maxNodes = static_cast<size_t>(0.35 * n) + 16;
-    DeviceBuffer boxes, cbounds, keysA, keysB, idxA, idxB, table, partials, left, right, parent, first, last, bounds,
+    DeviceBuffer scratch, boxes, cbounds, keysA, keysB, idxA, idxB, table, partials, left, right, parent, first, last, bounds,
         arrivals, frontierA, frontierB, nodeCounts, triCounts, tempNodes, rootBox;
-    RT_TRY(boxes.allocate(sizeof(Box4) * n));
-    RT_TRY(cbounds.allocate(sizeof(uint32_t) * 6));
-    RT_TRY(keysA.allocate(sizeof(uint64_t) * n));
-    RT_TRY(keysB.allocate(sizeof(uint64_t) * n));
-    RT_TRY(idxA.allocate(sizeof(uint32_t) * n));
-    RT_TRY(idxB.allocate(sizeof(uint32_t) * n));
-    RT_TRY(table.allocate(sizeof(uint32_t) * sortTableEntries(n)));
     const size_t scanEntries = std::max({scanScratchEntries(sortTableEntries(n)), scanScratchEntries(maxNodes + 1),
                                          scanScratchEntries(static_cast<size_t>(n) + 1)});
-    RT_TRY(partials.allocate(sizeof(uint32_t) * scanEntries));
-    RT_TRY(left.allocate(sizeof(uint32_t) * n));
-    RT_TRY(right.allocate(sizeof(uint32_t) * n));
-    RT_TRY(parent.allocate(sizeof(uint32_t) * ids));
-    RT_TRY(first.allocate(sizeof(uint32_t) * n));
-    RT_TRY(last.allocate(sizeof(uint32_t) * n));
-    RT_TRY(bounds.allocate(sizeof(Box4) * ids));
-    RT_TRY(arrivals.allocate(sizeof(uint32_t) * n));
-    RT_TRY(frontierA.allocate(sizeof(uint32_t) * maxNodes));
-    RT_TRY(frontierB.allocate(sizeof(uint32_t) * maxNodes));
-    RT_TRY(nodeCounts.allocate(sizeof(uint32_t) * (maxNodes + 1)));
-    RT_TRY(triCounts.allocate(sizeof(uint32_t) * (maxNodes + 1)));
-    RT_TRY(tempNodes.allocate(sizeof(WideNode) * maxNodes));
-    RT_TRY(rootBox.allocate(sizeof(Box4)));
+    RT_TRY(allocateTogether(scratch, {{&boxes, sizeof(Box4) * n},
+                                      {&cbounds, sizeof(uint32_t) * 6},
+                                      {&keysA, sizeof(uint64_t) * n},
+                                      {&keysB, sizeof(uint64_t) * n},
+                                      {&idxA, sizeof(uint32_t) * n},
+                                      {&idxB, sizeof(uint32_t) * n},
+                                      {&table, sizeof(uint32_t) * sortTableEntries(n)},
+                                      {&partials, sizeof(uint32_t) * scanEntries},
+                                      {&left, sizeof(uint32_t) * n},
+                                      {&right, sizeof(uint32_t) * n},
+                                      {&parent, sizeof(uint32_t) * ids},
+                                      {&first, sizeof(uint32_t) * n},
+                                      {&last, sizeof(uint32_t) * n},
+                                      {&bounds, sizeof(Box4) * ids},
+                                      {&arrivals, sizeof(uint32_t) * n},
+                                      {&frontierA, sizeof(uint32_t) * maxNodes},
+                                      {&frontierB, sizeof(uint32_t) * maxNodes},
+                                      {&nodeCounts, sizeof(uint32_t) * (maxNodes + 1)},
+                                      {&triCounts, sizeof(uint32_t) * (maxNodes + 1)},
+                                      {&tempNodes, sizeof(WideNode) * maxNodes},
+                                      {&rootBox, sizeof(Box4)}}));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&blas->triangles), sizeof(PackedTriangle) * n));
 
+    phase("allocations");
     {
         // cbounds doubles as the flag of the index check before it takes the centroid bounds
         RT_HIP(hipMemsetAsync(cbounds.data, 0, sizeof(uint32_t), stream));
@@ -1186,6 +1237,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_TRY(radixSortPairs<uint64_t>(keys, idx, n, 63, table.as<uint32_t>(), partials.as<uint32_t>(), stream, &result));
     const uint64_t* sortedKeys = keys[result];
     const uint32_t* order = idx[result];
+    phase("bounds, codes, sort");
 
     hipLaunchKernelGGL(leafBoundsKernel, dim3(blocks), dim3(256), 0, stream, boxes.as<Box4>(), order, n,
                        bounds.as<Box4>());
@@ -1253,18 +1305,17 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         RT_TRY(readyA.allocate(sizeof(uint32_t) * n));
         RT_TRY(readyB.allocate(sizeof(uint32_t) * n));
         RT_TRY(readyCounts.allocate(sizeof(uint32_t) * (kRefitMaxLevels + 1U)));
-        RT_HIP(hipMemsetAsync(arrivals.data, 0, sizeof(uint32_t) * n, stream));
         RT_HIP(hipMemsetAsync(readyCounts.data, 0, sizeof(uint32_t) * (kRefitMaxLevels + 1U), stream));
-        hipLaunchKernelGGL(refitLeavesKernel, dim3(blocks), dim3(256), 0, stream, parent.as<uint32_t>(), n,
+        hipLaunchKernelGGL(refitSeedKernel, dim3(divUp(n, kRefitBlock)), dim3(kRefitBlock), 0, stream, left.as<uint32_t>(), right.as<uint32_t>(), n,
                            arrivals.as<uint32_t>(), readyA.as<uint32_t>(), readyCounts.as<uint32_t>());
         uint32_t* listIn = readyA.as<uint32_t>();
         uint32_t* listOut = readyB.as<uint32_t>();
         // a level holds at most half the nodes of the one below; the grid-stride loop covers any list
-        const unsigned levelBlocks = std::max(1U, std::min(blocks, 2048U));
+        const unsigned levelBlocks = std::max(1U, std::min<unsigned>(divUp(n, kRefitBlock), 1024U));
         bool finished = false;
         for (uint32_t level = 0; level < kRefitMaxLevels && !finished; level += kRefitBatch) {
             for (uint32_t k = level; k < level + kRefitBatch; ++k) {
-                hipLaunchKernelGGL(refitLevelKernel, dim3(levelBlocks), dim3(256), 0, stream, left.as<uint32_t>(),
+                hipLaunchKernelGGL(refitLevelKernel, dim3(levelBlocks), dim3(kRefitBlock), 0, stream, left.as<uint32_t>(),
                                    right.as<uint32_t>(), parent.as<uint32_t>(), bounds.as<Box4>(),
                                    arrivals.as<uint32_t>(), listIn, listOut, readyCounts.as<uint32_t>(), k);
                 std::swap(listIn, listOut);
@@ -1279,6 +1330,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
             return failInvalid("bounds pass did not finish");
         probing = allowRefine && refineChoice() && n >= 64U;
     }
+    phase("binary tree and its boxes");
     RT_HIP(hipGetLastError());
     // The surface-area rebuild of the upper levels runs beside the collapse of the tree as it is (UpperRefinement);
     // if the rebuilt levels are taken, the collapse runs again over them.
@@ -1338,6 +1390,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     return RT_SUCCESS;
     };
     RT_TRY(collapse());
+    phase("collapse");
     if (probing) {
         bool replaced = false;
         RT_TRY(refinement.finish(order, idx[1 - result], replaced));
@@ -1355,6 +1408,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_HIP(hipMemcpyAsync(&root, rootBox.data, sizeof(root), hipMemcpyDeviceToHost, stream));
     RT_HIP(hipEventRecord(stop, stream));
     RT_HIP(hipStreamSynchronize(stream));
+    phase("second collapse, node copy");
     RT_HIP(hipEventElapsedTime(&blas->buildMilliseconds, start, stop));
     (void)hipEventDestroy(start);
     (void)hipEventDestroy(stop);
