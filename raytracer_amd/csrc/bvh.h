@@ -143,6 +143,13 @@ struct rt_scene {
     // dealt the slot makes its stream wait for that event before it zeroes the cursors, so launches on
     // different streams never share a set however many are in flight.
     uint32_t* feedCursors = nullptr;
+    rt::Aabb bounds{};                       // world-space box of everything in the scene (host copy)
+    // Workspace of the ordering step of large batched queries (see orderRays in traverse.hip): grown on demand,
+    // handed to one launch at a time under feedMutex, the next user's stream waits for orderEvent.
+    mutable void* orderData = nullptr;
+    mutable size_t orderBytes = 0;
+    mutable hipEvent_t orderEvent = nullptr;
+    mutable bool orderEventRecorded = false;
     mutable hipEvent_t feedEvents[rt::kFeedSlots] = {};
     mutable bool feedEventRecorded[rt::kFeedSlots] = {};
     mutable uint32_t feedNext = 0;

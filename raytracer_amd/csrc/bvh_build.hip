@@ -22,6 +22,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -976,11 +977,18 @@ struct UpperBuilder {
         nodes[base].triangles = triangles;
         const uint32_t leftBase = base + 1U, rightBase = base + (middle - begin);
         uint32_t l, r;
+        bool forked = false;
         if (level < kForkLevels && end - begin >= kForkMinimum) {
-            std::thread other([&] { l = build(begin, middle, leftBase, level + 1U); });
-            r = build(middle, end, rightBase, level + 1U);
-            other.join();
-        } else {
+            try {
+                std::thread other([&] { l = build(begin, middle, leftBase, level + 1U); });
+                forked = true;
+                r = build(middle, end, rightBase, level + 1U);
+                other.join();
+            } catch (const std::system_error&) {
+                // no thread to be had: this one does both halves
+            }
+        }
+        if (!forked) {
             l = build(begin, middle, leftBase, level + 1U);
             r = build(middle, end, rightBase, level + 1U);
         }
@@ -1088,7 +1096,11 @@ struct UpperRefinement {
             return failInvalid("the root is not among the upper nodes");
         mark("clusters to the host");
         builder = std::make_unique<UpperBuilder>(clusters);
-        worker = std::thread([this] { builder->build(0, clusterCount); });
+        try {
+            worker = std::thread([this] { builder->build(0, clusterCount); });
+        } catch (const std::system_error&) {
+            builder->build(0, clusterCount);  // no thread to be had: the rebuild runs here, ahead of the collapse
+        }
         started = true;
         return RT_SUCCESS;
     }
@@ -1796,7 +1808,8 @@ rt_status buildScene(const rt_instance_desc* instances, uint32_t count, hipStrea
     builder.budget = levels;
     if (const char* v = std::getenv("RT_SCENE_FOLD"))
         builder.pairs = std::strcmp(v, "single") != 0;
-    builder.build(0, {0, itemCount, builder.boxOf(0, itemCount)}, 0);
+    scene->bounds = builder.boxOf(0, itemCount);
+    builder.build(0, {0, itemCount, scene->bounds}, 0);
     std::vector<InstanceRecord> ordered(itemCount);
     if (builder.items.size() != itemCount)
         return failInvalid("top-level build lost instances");
@@ -1928,6 +1941,10 @@ void rt_scene_destroy(rt_scene* scene) {
         (void)hipFree(scene->shadeInstances);
     if (scene->hitGroups)
         (void)hipFree(scene->hitGroups);
+    if (scene->orderData)
+        (void)hipFree(scene->orderData);
+    if (scene->orderEvent)
+        (void)hipEventDestroy(scene->orderEvent);
     delete scene;
 }
 

@@ -463,3 +463,39 @@ def test_geometry_records_must_cover_every_instance(engine):
         assert "materials" in str(failure.value)
     finally:
         lib.rt_wavefront_destroy(state)
+
+
+def test_rays_ordered_by_origin_report_the_same_hits(engine, oracle):
+    """A large batch over a large scene is traced through an index sorted by origin cell (RT_TRACE_ORDER=1 does
+    it for any batch): every ray's result stays at the ray's own place and is what it was, NaN origins and ragged
+    sizes included, for both kinds of query and from two streams at once."""
+    import os
+    import torch
+    scene = workloads.triangle_soup(100000)
+    top, blases = engine_scene(engine, scene)
+    ref = oracle_scene(oracle, scene)
+    o, d = workloads.random_rays(scene, 300001, seed=31)
+    o[5:40, 0] = np.float32("nan")
+    o[40:80, :3] += np.float32(1e6)   # far outside the scene's box
+    od, dd = dev(o), dev(d)
+    plain, pinst = top.trace_closest(od, dd)
+    shadow = top.trace_any(od, dd)
+    os.environ["RT_TRACE_ORDER"] = "1"
+    try:
+        for n in (300001, 65, 64, 2):
+            hits, inst = top.trace_closest(od[:n].contiguous(), dd[:n].contiguous())
+            assert torch.equal(hits.view(torch.int32), plain[:n].view(torch.int32)) and torch.equal(inst, pinst[:n])
+            assert torch.equal(top.trace_any(od[:n].contiguous(), dd[:n].contiguous()), shadow[:n])
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        results = []
+        for k in range(6):
+            with torch.cuda.stream(streams[k & 1]):
+                results.append(top.trace_closest(od, dd, stream=streams[k & 1]))
+        torch.cuda.synchronize()
+        for hits, inst in results:
+            assert torch.equal(hits.view(torch.int32), plain.view(torch.int32)) and torch.equal(inst, pinst)
+    finally:
+        del os.environ["RT_TRACE_ORDER"]
+    tuv, prim, rinst = ref.trace_closest(o, d, use_bvh=True, threads=8)
+    bad, report = compare_closest(plain, pinst, tuv, prim, rinst)
+    assert bad == 0, report
