@@ -1170,9 +1170,19 @@ struct UpperRefinement {
 
 rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride, const uint32_t* indices, uint32_t n,
                     hipStream_t stream, rt_blas* blas, bool allowRefine = true) {
-    hipEvent_t start, stop;
-    RT_HIP(hipEventCreate(&start));
-    RT_HIP(hipEventCreate(&stop));
+    // the two events of the build's own time; released on every way out
+    struct Events {
+        hipEvent_t start = nullptr, stop = nullptr;
+        ~Events() {
+            if (start)
+                (void)hipEventDestroy(start);
+            if (stop)
+                (void)hipEventDestroy(stop);
+        }
+    } events;
+    RT_HIP(hipEventCreate(&events.start));
+    RT_HIP(hipEventCreate(&events.stop));
+    const hipEvent_t start = events.start, stop = events.stop;
     RT_HIP(hipEventRecord(start, stream));
 
     // RT_BLAS_TIMING=1 prints where the time of a build goes (host clock, the stream waited for at each mark)
@@ -1227,8 +1237,6 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         RT_HIP(hipMemcpyAsync(&bad, cbounds.data, sizeof(bad), hipMemcpyDeviceToHost, stream));
         RT_HIP(hipStreamSynchronize(stream));
         if (bad) {
-            (void)hipEventDestroy(start);
-            (void)hipEventDestroy(stop);
             (void)hipFree(blas->triangles);
             blas->triangles = nullptr;
             return failInvalid("a triangle index is not below the vertex count");
@@ -1422,8 +1430,6 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     RT_HIP(hipStreamSynchronize(stream));
     phase("second collapse, node copy");
     RT_HIP(hipEventElapsedTime(&blas->buildMilliseconds, start, stop));
-    (void)hipEventDestroy(start);
-    (void)hipEventDestroy(stop);
     blas->bounds = {{root.lo.x, root.lo.y, root.lo.z}, {root.hi.x, root.hi.y, root.hi.z}};
     return RT_SUCCESS;
 }
@@ -1874,8 +1880,10 @@ rt_status rt_blas_build(const void* vertices, uint32_t vertexCount, uint32_t ver
         return failInvalid("vertex stride must be a multiple of 4 and at least 12");
     if (triangleCount > (1U << 28) - 2U)
         return failInvalid("too many triangles");
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
     auto* blas = new rt_blas();
-    RT_HIP(hipGetDevice(&blas->device));
+    blas->device = device;
     rt_status status = buildBlas(vertices, vertexCount, vertexStride, indices, triangleCount,
                                  static_cast<hipStream_t>(stream), blas);
     // The surface-area rebuild of the upper levels follows the boxes, not the count, and can come out deeper than
