@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
+# Collects the rocprofv3 evidence for one tag on the GPU box (run through gpurun from the repo root):
 #   profiles/run_profile.sh <tag>
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2-4: PMC counters, one block per
 # run (FETCH_SIZE / WRITE_SIZE / L2 hit+miss), never combined with other trace domains.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects one round's profiles on the GPU box: profiles/run_profile.sh <tag>, the SQ counters of the ray
+# Collects the profiles of one tag on the GPU box: profiles/run_profile.sh <tag>, the SQ counters of the ray
 # kernels, and the counter calibration kernels.  Results under gpurun_out/; summarise afterwards here.
 set -e
 TAG=${1:-r2}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiles on the GPU box (run through gpurun from the repo root): tools/profile_round3.sh <part>
+# Profiles of the library in the tree, collected on the GPU box (run through gpurun from the repo root): tools/profile_round3.sh <part>
 #   bench : profiles/run_profile.sh (kernel trace + FETCH / WRITE / L2 passes of the default bench) and the SQ counters
 #   soup  : kernel trace + FETCH_SIZE + WRITE_SIZE + L2 of the triangle soups, ONE SIZE PER RUN, so that the counters
 #           of a size are the means of that size's launches alone
