@@ -314,7 +314,7 @@ rt_status rt_trace_photons(rt_wavefront* wavefront, const rt_launch_params* para
  * used.  Photon i of pass k draws the streams seeded (i, photonPass + k)
  * (src/device.cu:772), so every list equals that of a pass traced alone.  As many
  * passes as the state holds (maxPaths / emissionCount) run side by side. */
-#define RT_MAX_PHOTON_PASSES 8
+#define RT_MAX_PHOTON_PASSES 16
 rt_status rt_trace_photon_passes(rt_wavefront* wavefront, const rt_launch_params* params, uint32_t firstEmission,
                                  uint32_t emissionCount, uint32_t passes, rt_photon* const* lists,
                                  uint32_t* const* counters, uint32_t* const* keys, void* stream);

@@ -57,6 +57,11 @@ namespace rt {
 #ifndef RT_TRACE_GRID_SCALE
 #define RT_TRACE_GRID_SCALE 1
 #endif
+// Whether a lane whose node step found no child takes its next stack entry before the leaf part of the same turn
+// (a leaf it finds there is then tested in this turn) or only at the end of the turn.
+#ifndef RT_TRACE_POP_AFTER_NODE
+#define RT_TRACE_POP_AFTER_NODE 1
+#endif
 #ifndef RT_TRACE_BLOCK
 #define RT_TRACE_BLOCK 256
 #endif
@@ -805,8 +810,10 @@ __device__ __forceinline__ void tracePersistent(Traversal<COUNT>& walk, RayFeed&
         }
         if (active) {
 #endif
+#if RT_TRACE_POP_AFTER_NODE
             if (walk.node == kPop)
                 walk.node = walk.pop();
+#endif
             if ((walk.node & 0xf0000000U) == kLeafBit)
                 walk.node = kPop;  // a leaf of no items: an empty slot that passed the slab test
             if ((walk.node & kLeafBit) && walk.node < kPop) {

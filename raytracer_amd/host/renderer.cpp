@@ -474,7 +474,7 @@ struct Renderer::Impl {
     // engine states per path, at most this much and at most half of the memory that is free when the state is made
     static constexpr std::uint64_t kStateBudget = 24ULL << 30;
     // a pass with a photon map holds at most this many groups of four samples
-    static constexpr std::uint32_t kMapsPerPass = 8;
+    static constexpr std::uint32_t kMapsPerPass = 16;  // RT_MAX_PHOTON_MAPS: what the gather kernels take a table of
     std::uint32_t measurementFlags = 0;
     // one region, four samples of it in flight: measured best on every workload (a 1080p sample's
     // launches leave the GPU half idle in their tails; four of them side by side fill it)
@@ -755,6 +755,15 @@ struct Renderer::Impl {
         const std::uint32_t perPass = batch % kPhotonRebuildInterval == 0U ? batch / kPhotonRebuildInterval
                                                                           : (batch + 6U) / kPhotonRebuildInterval;
         return static_cast<std::size_t>(std::max(perPass, 1U)) * depth;
+    }
+
+    // Bytes of the photon pool for passes of `samples` samples (whole groups of four): see allocateMaps.
+    std::uint64_t photonPoolBytes(std::uint32_t samples) const {
+        const std::uint64_t listBytes = static_cast<std::uint64_t>(launch.photonCapacity) * sizeof(rt_photon);
+        const std::uint64_t tableBytes = (static_cast<std::uint64_t>(launch.photonBucketCount) + 1U) * sizeof(std::uint32_t);
+        const std::uint64_t perPass = std::max<std::uint32_t>(samples / kPhotonRebuildInterval, 1U);
+        const std::uint64_t lists = std::min<std::uint64_t>(perPass, RT_MAX_PHOTON_PASSES);
+        return perPass * depth * (listBytes + tableBytes + launch.photonBucketCount / 8U) + lists * listBytes;
     }
 
     // Photon passes traced together: those of the maps one camera pass gathers from (when its samples are whole
@@ -1173,6 +1182,12 @@ struct Renderer::Impl {
             const std::uint64_t budget = std::min<std::uint64_t>(kStateBudget, freeBytes / 2U);
             batch = caustics ? kMapsPerPass * kPhotonRebuildInterval : 64U;
             while (batch > 1 && stateBytes(capacity * batch) * count * depth > budget)
+                batch /= 2;
+            // the photon maps of the passes in flight and the lists of the passes traced together have a budget of
+            // their own: a pass of 64 samples gathers from sixteen maps, two such passes from thirty-two (10 GiB at
+            // the reference's sizes)
+            const std::uint64_t photonBudget = std::min<std::uint64_t>(16ULL << 30, freeBytes / 4U);
+            while (caustics && batch > kPhotonRebuildInterval && photonPoolBytes(batch) > photonBudget)
                 batch /= 2;
         }
         for (;;) {

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "librt_host.so")
 
 PREVIEW, FINAL = 0, 1
+MAX_PHOTON_PASSES = 16  # RT_MAX_PHOTON_PASSES: photon passes the renderer may trace together
 
 
 class Float2(C.Structure):
@@ -482,12 +483,12 @@ class Renderer:
 
     def trace_photon_range_passes(self, first, count, passes, staging=False):
         """The emission range for every begun pass; returns the stored count per pass."""
-        stored = (_u32 * 8)()
+        stored = (_u32 * MAX_PHOTON_PASSES)()
         _check(load().rth_renderer_trace_photon_range_passes(self.handle, first, count, int(staging), stored))
         return [int(stored[k]) for k in range(passes)]
 
     def finish_photon_passes(self, totals):
-        values = (_u32 * 8)(*totals)
+        values = (_u32 * MAX_PHOTON_PASSES)(*totals)
         _check(load().rth_renderer_finish_photon_passes(self.handle, values))
 
     def output_buffer(self):

@@ -551,6 +551,22 @@ def test_sample_batches_do_not_change_the_image(R):
         assert r.statistics()["gather_queries"] > 0
     for buffers in shots[1:]:
         assert np.array_equal(buffers, shots[0])
+    # a pass of 64 samples gathers from sixteen maps, the photon passes of which are traced together; 137 samples are
+    # two such passes and a short one
+    shots = []
+    for batch, depth in ((4, 1), (64, 2), (0, 0)):
+        r = R.Renderer(scene, w, h, 1)
+        r.set_photon_budget(1 << 17, 1 << 16, 1 << 12)
+        r.set_concurrent_tiles(1, depth)
+        r.set_sample_batch(batch)
+        for _ in range(137):
+            r.render()
+        r.synchronize()
+        if batch == 64:
+            assert r.photon_passes_together() == 16
+        shots.append(np.stack([R.device_to_host(r.accumulation_buffer(k), w * h * 16) for k in range(7)]))
+    for buffers in shots[1:]:
+        assert np.array_equal(buffers, shots[0])
     # shares of a frame
     scene = workloads.cornell_box(light="panel")
     w, h = 64, 72
