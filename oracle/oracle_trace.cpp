@@ -204,10 +204,15 @@ bool hitBox(const Box& b, V3 o, const float* invd, float tmin, float tmax) {
     return tn * (1.0f - 0x1p-20f) <= tf * (1.0f + 0x1p-20f);
 }
 
+// The margin comes from the largest coordinate of the box and goes on every axis: the distance the triangle test
+// computes is off by a few ulps of the triangle's size, not of the distance, and a box without extent along an axis
+// (a floor at y = 0) would otherwise have no margin there at all.
 void padBox(Box& b) {
+    float m = 0.0f;
+    for (int a = 0; a < 3; ++a)
+        m = std::max(m, std::max(std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])), b.hi[a] - b.lo[a]));
+    const float pad = std::max(m * 0x1p-18f, 1e-30f);
     for (int a = 0; a < 3; ++a) {
-        const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-        const float pad = std::max(m * 0x1p-20f, 1e-30f);
         b.lo[a] -= pad;
         b.hi[a] += pad;
     }
@@ -590,9 +595,11 @@ void orc_scene_commit(orc_scene* s) {
         }
         // the object-space test sees the ray through the rounded inverse, so
         // leave a wider margin than for object-space boxes
+        float m = 0.0f;
+        for (int a = 0; a < 3; ++a)
+            m = std::max(m, std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a])) + (box.hi[a] - box.lo[a]));
+        const float pad = std::max(m * 0x1p-16f, 1e-30f);
         for (int a = 0; a < 3; ++a) {
-            const float m = std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a]));
-            const float pad = std::max((m + (box.hi[a] - box.lo[a])) * 0x1p-16f, 1e-30f);
             box.lo[a] -= pad;
             box.hi[a] += pad;
         }

@@ -1481,9 +1481,12 @@ Aabb instanceBox(const float* m, const Aabb& object) {
             box.hi[a] = std::max(box.hi[a], static_cast<float>(std::nextafter(static_cast<float>(v), INFINITY)));
         }
     }
+    // from the largest coordinate, on every axis (see boxMargin: an instance may be as flat as a triangle)
+    float m2 = 0.0f;
+    for (int a = 0; a < 3; ++a)
+        m2 = std::max(m2, std::max(std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a])), box.hi[a] - box.lo[a]));
+    const float pad = std::max(m2 * 0x1p-16f, 1e-30f);
     for (int a = 0; a < 3; ++a) {
-        const float m2 = std::max(std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a])), box.hi[a] - box.lo[a]);
-        const float pad = std::max(m2 * 0x1p-16f, 1e-30f);
         box.lo[a] -= pad;
         box.hi[a] += pad;
     }

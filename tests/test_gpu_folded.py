@@ -128,3 +128,34 @@ def test_interval_that_ends_at_a_hit_on_a_flat_mesh(engine, fold):
     closed[found, 3] = hits[:, 0][found]
     same, _ = top.trace_closest(od, closed)
     assert torch.equal(same[found].view(torch.int32), hits[found].view(torch.int32))
+
+
+def test_origins_on_the_geometry(engine, oracle):
+    """Rays that start on the plane of a flat mesh or on a face of an instance's box, tmin = 0, against flat meshes
+    that are folded (identity) and entered (shifted along their own plane): the oracle's brute force decides."""
+    rng = np.random.default_rng(11)
+    floor = workloads.quad([-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1])
+    wall = workloads.quad([0, -1, -1], [0, 1, -1], [0, 1, 1], [0, -1, 1])
+    box = workloads.box_mesh([-0.5, -0.25, -0.75], [0.25, 0.5, 0.125])
+    geometries = [{"vertices": m[0], "indices": m[1], "material": 0} for m in (floor, wall, box)]
+    shift = np.eye(4, dtype=np.float32)
+    shift[3, :3] = (0.375, 0.0, -0.25)
+    scene = dict(geometries=geometries, instances=[(0, np.eye(4, dtype=np.float32).reshape(-1)), (1, shift.reshape(-1)),
+                                                   (2, np.eye(4, dtype=np.float32).reshape(-1)), (0, shift.reshape(-1))])
+    top, blases = engine_scene(engine, scene)
+    assert top.folded() == (2, 14)
+    ref = oracle_scene(oracle, scene)
+    n = 200000
+    o, d = workloads.random_rays(scene, n, seed=3)
+    planes = np.array([0.0, 0.375, -0.5, 0.25, -0.25, 0.5, -0.75, 0.125, 1.0, -1.0], dtype=np.float32)
+    axis = rng.integers(0, 3, n)
+    o[np.arange(n), axis] = planes[rng.integers(0, len(planes), n)]
+    o[:, 3] = 0.0
+    hits, inst = top.trace_closest(dev(o), dev(d))
+    tuv, prim, rinst = ref.trace_closest(o, d, use_bvh=False, threads=8)
+    bad, report = compare_closest(hits, inst, tuv, prim, rinst)
+    assert bad == 0, f"{bad} of {n} rays differ: {report}"
+    plain, _ = unfolded(engine, scene)
+    same, sinst = plain.trace_closest(dev(o), dev(d))
+    bad, report = compare_closest(same, sinst, tuv, prim, rinst)
+    assert bad == 0, f"not folded: {bad} of {n} rays differ: {report}"

@@ -108,6 +108,33 @@ def test_bvh_equals_bruteforce(oracle):
         assert np.array_equal(s.trace_any(o, d, use_bvh=True, threads=8), (a[1] != 0xffffffff).astype(np.uint8))
 
 
+def test_bvh_equals_bruteforce_from_origins_on_the_geometry(oracle):
+    """Rays that start on coordinates the scene itself uses - on the plane of a flat mesh, on a face of an
+    instance's box - with tmin = 0: the hit sits a few ulps of the triangle's size from the origin, and a box whose
+    margin came from the coordinates of its own axis alone (nothing, for a floor at 0) would turn the ray away."""
+    rng = np.random.default_rng(11)
+    floor = workloads.quad([-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1])
+    wall = workloads.quad([0, -1, -1], [0, 1, -1], [0, 1, 1], [0, -1, 1])
+    box = workloads.box_mesh([-0.5, -0.25, -0.75], [0.25, 0.5, 0.125])
+    geometries = [{"vertices": m[0], "indices": m[1], "material": 0} for m in (floor, wall, box)]
+    shift = np.eye(4, dtype=np.float32)
+    shift[3, :3] = (0.375, 0.0, -0.25)  # column-major: a translation that keeps the floor at y = 0
+    scene = dict(geometries=geometries, instances=[(0, np.eye(4, dtype=np.float32).reshape(-1)), (1, shift.reshape(-1)),
+                                                   (2, np.eye(4, dtype=np.float32).reshape(-1)), (0, shift.reshape(-1))])
+    s = oracle_scene(oracle, scene)
+    n = 60000
+    o, d = workloads.random_rays(scene, n, seed=3)
+    planes = np.array([0.0, 0.375, -0.5, 0.25, -0.25, 0.5, -0.75, 0.125, 1.0, -1.0], dtype=np.float32)
+    axis = rng.integers(0, 3, n)
+    o[np.arange(n), axis] = planes[rng.integers(0, len(planes), n)]
+    o[:, 3] = 0.0
+    a = s.trace_closest(o, d, use_bvh=False, threads=8)
+    b = s.trace_closest(o, d, use_bvh=True, threads=8)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert ((a[0][:, 0] > 0) & (a[0][:, 0] < 1e-5)).sum() > 10  # some hits do sit that close to their origins
+
+
 def test_hit_attributes(oracle):
     scene = workloads.cornell_box()
     s = oracle_scene(oracle, scene)
