@@ -632,7 +632,7 @@ __global__ __launch_bounds__(128) void collapseCountKernel(const uint32_t* front
                                                            const uint32_t* left, const uint32_t* right,
                                                            const uint32_t* first, const uint32_t* last,
                                                            const Box4* bounds, uint32_t* nodeCounts,
-                                                           uint32_t* triCounts) {
+                                                           uint32_t* triCounts, uint2* gathered) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e > entries)
         return;
@@ -652,6 +652,16 @@ __global__ __launch_bounds__(128) void collapseCountKernel(const uint32_t* front
     }
     nodeCounts[e] = nodes;
     triCounts[e] = tris;
+    // what was gathered, for pass B: (id, triangles of a leaf child or 0) and the first triangle, kNoHit ends the list
+    static_assert(kMaxLeaf <= 7, "the triangle count of a leaf child travels in three bits");
+    for (int k = 0; k < kWide; ++k) {
+        uint2 record = make_uint2(kNoHit, 0U);
+        if (k < count) {
+            const uint32_t leaf = children[k].count <= static_cast<uint32_t>(kMaxLeaf) ? children[k].count : 0U;
+            record = make_uint2(children[k].id | leaf << 29, children[k].first);
+        }
+        gathered[static_cast<size_t>(e) * kWide + k] = record;
+    }
 }
 
 __device__ inline float scaleOf(uint8_t e) {
@@ -689,13 +699,25 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
     const uint32_t* frontier, uint32_t entries, uint32_t n, const uint32_t* left, const uint32_t* right,
     const uint32_t* first, const uint32_t* last, const Box4* bounds, const uint32_t* nodeOffsets,
     const uint32_t* triOffsets, uint32_t levelNodeBase, uint32_t nextNodeBase, uint32_t triBase,
-    const uint32_t* order, const uint8_t* vertices, uint32_t stride, const uint32_t* indices, WideNode* nodes,
-    PackedTriangle* triangles, uint32_t* nextFrontier, Box4* rootBox) {
+    const uint32_t* order, WideNode* nodes, uint32_t* slotPrimitive, uint32_t* nextFrontier, Box4* rootBox,
+    const uint2* gathered) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= entries)
         return;
+    // the children pass A gathered for this entry
     Child children[kWide];
-    const int count = gatherChildren(frontier[e], n, left, right, first, last, bounds, children);
+    int count = 0;
+    for (int k = 0; k < kWide; ++k) {
+        const uint2 record = gathered[static_cast<size_t>(e) * kWide + k];
+        if (record.x == kNoHit)
+            break;
+        const uint32_t leaf = record.x >> 29;
+        children[k].id = record.x & 0x1fffffffU;
+        children[k].first = record.y;
+        children[k].count = leaf ? leaf : static_cast<uint32_t>(kMaxLeaf) + 1U;  // pass B only asks: leaf of how many, or not
+        children[k].area = 0.0f;
+        count = k + 1;
+    }
 
     Box4 boxes[kWide];
     Box4 all;
@@ -751,17 +773,9 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
             ++nodeSlot;
         } else {
             node.meta[k] = static_cast<uint8_t>(children[k].count << 5 | triSlot);
-            for (uint32_t t = 0; t < children[k].count; ++t) {
-                const uint32_t prim = order[children[k].first + t];
-                const float3 a = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim)]);
-                const float3 b = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 1]);
-                const float3 c = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 2]);
-                PackedTriangle tri;
-                tri.v0[0] = a.x; tri.v0[1] = a.y; tri.v0[2] = a.z; tri.primitive = prim;
-                tri.v1[0] = b.x; tri.v1[1] = b.y; tri.v1[2] = b.z; tri.pad1 = 0;
-                tri.v2[0] = c.x; tri.v2[1] = c.y; tri.v2[2] = c.z; tri.pad2 = 0;
-                triangles[primBase + triSlot + t] = tri;
-            }
+            // which triangle goes to which slot; packTrianglesKernel fetches the corners, one thread per slot
+            for (uint32_t t = 0; t < children[k].count; ++t)
+                slotPrimitive[primBase + triSlot + t] = order[children[k].first + t];
             triSlot += children[k].count;
         }
     }
@@ -772,6 +786,26 @@ __global__ __launch_bounds__(128) void collapseEmitKernel(
             node.qhi[a][k] = 0;
         }
     nodes[levelNodeBase + e] = node;
+}
+
+// The triangle records of the leaves, one thread per slot of the triangle array: the corners of the triangle
+// the collapse assigned to the slot (a thread of the collapse has up to sixteen slots to fill; fetching their
+// corners there, one dependent chain after the other, was a third of its time).
+__global__ __launch_bounds__(256) void packTrianglesKernel(const uint32_t* slotPrimitive, uint32_t n, const uint8_t* vertices,
+                                                           uint32_t stride, const uint32_t* indices,
+                                                           PackedTriangle* triangles) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n)
+        return;
+    const uint32_t prim = slotPrimitive[slot];
+    const float3 a = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim)]);
+    const float3 b = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 1]);
+    const float3 c = loadPosition(vertices, stride, indices[3 * static_cast<size_t>(prim) + 2]);
+    PackedTriangle tri;
+    tri.v0[0] = a.x; tri.v0[1] = a.y; tri.v0[2] = a.z; tri.primitive = prim;
+    tri.v1[0] = b.x; tri.v1[1] = b.y; tri.v1[2] = b.z; tri.pad1 = 0;
+    tri.v2[0] = c.x; tri.v2[1] = c.y; tri.v2[2] = c.z; tri.pad2 = 0;
+    triangles[slot] = tri;
 }
 
 // ---- host side --------------------------------------------------------------
@@ -1199,7 +1233,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     const uint32_t ids = 2U * n - 1U;
     const size_t maxNodes = static_cast<size_t>(0.35 * n) + 16;
     DeviceBuffer scratch, boxes, cbounds, keysA, keysB, idxA, idxB, table, partials, left, right, parent, first, last, bounds,
-        arrivals, frontierA, frontierB, nodeCounts, triCounts, tempNodes, rootBox;
+        arrivals, frontierA, frontierB, nodeCounts, triCounts, tempNodes, rootBox, gathered;
     const size_t scanEntries = std::max({scanScratchEntries(sortTableEntries(n)), scanScratchEntries(maxNodes + 1),
                                          scanScratchEntries(static_cast<size_t>(n) + 1)});
     RT_TRY(allocateTogether(scratch, {{&boxes, sizeof(Box4) * n},
@@ -1222,7 +1256,8 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
                                       {&nodeCounts, sizeof(uint32_t) * (maxNodes + 1)},
                                       {&triCounts, sizeof(uint32_t) * (maxNodes + 1)},
                                       {&tempNodes, sizeof(WideNode) * maxNodes},
-                                      {&rootBox, sizeof(Box4)}}));
+                                      {&rootBox, sizeof(Box4)},
+                                      {&gathered, sizeof(uint2) * kWide * maxNodes}}));
     RT_HIP(hipMalloc(reinterpret_cast<void**>(&blas->triangles), sizeof(PackedTriangle) * n));
 
     phase("allocations");
@@ -1367,6 +1402,8 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     // top-down collapse, one level per iteration
     uint32_t levelNodeBase = 0, depth = 0;
     auto collapse = [&]() -> rt_status {
+    // slot -> triangle, in whichever of the sort's two index arrays does not hold the triangle order
+    uint32_t* slotPrimitive = order == idx[0] ? idx[1] : idx[0];
     uint32_t* frontier = frontierA.as<uint32_t>();
     uint32_t* nextFrontier = frontierB.as<uint32_t>();
     const uint32_t rootId = 0;  // internal node 0, or leaf 0 when n == 1 (id n-1 = 0)
@@ -1379,7 +1416,7 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
             return failInvalid("wide-node estimate exceeded");
         hipLaunchKernelGGL(collapseCountKernel, dim3(divUp(entries + 1, 128)), dim3(128), 0, stream, frontier, entries,
                            n, left.as<uint32_t>(), right.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(),
-                           bounds.as<Box4>(), nodeCounts.as<uint32_t>(), triCounts.as<uint32_t>());
+                           bounds.as<Box4>(), nodeCounts.as<uint32_t>(), triCounts.as<uint32_t>(), gathered.as<uint2>());
         RT_TRY(exclusiveScanU32(nodeCounts.as<uint32_t>(), nodeCounts.as<uint32_t>(), entries + 1,
                                 partials.as<uint32_t>(), stream));
         RT_TRY(exclusiveScanU32(triCounts.as<uint32_t>(), triCounts.as<uint32_t>(), entries + 1,
@@ -1396,8 +1433,8 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
         hipLaunchKernelGGL(collapseEmitKernel, dim3(divUp(entries, 128)), dim3(128), 0, stream, frontier, entries, n,
                            left.as<uint32_t>(), right.as<uint32_t>(), first.as<uint32_t>(), last.as<uint32_t>(),
                            bounds.as<Box4>(), nodeCounts.as<uint32_t>(), triCounts.as<uint32_t>(), levelNodeBase,
-                           nextNodeBase, triBase, order, vbytes, stride, indices, tempNodes.as<WideNode>(),
-                           blas->triangles, nextFrontier, depth == 0 ? rootBox.as<Box4>() : nullptr);
+                           nextNodeBase, triBase, order, tempNodes.as<WideNode>(), slotPrimitive, nextFrontier,
+                           depth == 0 ? rootBox.as<Box4>() : nullptr, gathered.as<uint2>());
         RT_HIP(hipGetLastError());
         levelNodeBase = nextNodeBase;
         triBase += totals[1];
@@ -1407,6 +1444,9 @@ rt_status buildBlas(const void* vertices, uint32_t vertexCount, uint32_t stride,
     }
     if (triBase != n)
         return failInvalid("collapse lost triangles");
+    hipLaunchKernelGGL(packTrianglesKernel, dim3(blocks), dim3(256), 0, stream, slotPrimitive, n, vbytes, stride, indices,
+                       blas->triangles);
+    RT_HIP(hipGetLastError());
     return RT_SUCCESS;
     };
     RT_TRY(collapse());
