@@ -147,6 +147,39 @@ __device__ inline void allocateSlotPair(bool wantA, uint32_t* counterA, bool wan
     slotB = shared[kSlotWords + kShadeWaves] + shared[kSlotWords + wave] + __popcll(votesB & below);
 }
 
+// Three queues at once (a shade launch with a photon map: next rays, shadow rays, photon queries).  `shared` holds
+// 3 * kSlotWords words.  The queries used to draw their slots where they arise, one atomic per wave on the queue's
+// length: half a million of them in the first bounce of a sixteen-sample pass, served one after the other at some
+// 11 ns apiece - 6 of the 12 ms of that launch.
+__device__ inline void allocateSlotTriple(bool wantA, uint32_t* counterA, bool wantB, uint32_t* counterB, bool wantC,
+                                          uint32_t* counterC, uint32_t* shared /* 3 * kSlotWords */, uint32_t& slotA,
+                                          uint32_t& slotB, uint32_t& slotC) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votesA = __ballot(wantA), votesB = __ballot(wantB), votesC = __ballot(wantC);
+    if (lane == 0) {
+        shared[wave] = __popcll(votesA);
+        shared[kSlotWords + wave] = __popcll(votesB);
+        shared[2 * kSlotWords + wave] = __popcll(votesC);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one thread totals each queue
+        uint32_t* counts = shared + kSlotWords * threadIdx.x;
+        uint32_t total = 0;
+        for (int w = 0; w < kShadeWaves; ++w) {
+            const uint32_t c = counts[w];
+            counts[w] = total;
+            total += c;
+        }
+        uint32_t* counter = threadIdx.x == 0 ? counterA : (threadIdx.x == 1 ? counterB : counterC);
+        counts[kShadeWaves] = total ? atomicAdd(counter, total) : 0U;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    slotA = shared[kShadeWaves] + shared[wave] + __popcll(votesA & below);
+    slotB = shared[kSlotWords + kShadeWaves] + shared[kSlotWords + wave] + __popcll(votesB & below);
+    slotC = shared[2 * kSlotWords + kShadeWaves] + shared[2 * kSlotWords + wave] + __popcll(votesC & below);
+}
+
 // ---- camera paths -----------------------------------------------------------
 
 // Which pixels a launch covers and how its paths are numbered.  The pixels are a run of
@@ -347,6 +380,9 @@ struct ShadeOut {
     float shadowLimit = 0.0f;
     uint32_t shadowBits = 0, targetInstance = kNoHit, targetPrimitive = kNoHit;
     uint32_t gatherQueries = 0, gathered = 0;  // INLINE_GATHER only
+    // the photon query of this bounce, for the launch's query queue
+    bool wantsGather = false;
+    V3 gatherPoint{0, 0, 0}, gatherNormal{0, 0, 0}, gatherThroughput{0, 0, 0}, gatherWeight{0, 0, 0};
     // the path's state behind the bounce (written next to its next ray when it continues)
     float4 throughputAfter{0, 0, 0, 0}, lastOriginAfter{0, 0, 0, 0};
     uint32_t rngAfter = 0;
@@ -479,18 +515,12 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
             out.gathered = gathered;
         } else {
             // the query is left for causticGatherKernel, which walks the photon map with dense
-            // waves instead of the few lanes that want it here
-            const unsigned long long votes = __ballot(1);
-            const int lane = threadIdx.x & 63;
-            uint32_t base = 0;
-            if (lane == __ffsll(static_cast<long long>(votes)) - 1)
-                base = atomicAdd(&b.counts[3], static_cast<uint32_t>(__popcll(votes)));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const uint32_t query = base + __popcll(votes & ((1ULL << lane) - 1ULL));
-            b.gather[0][query] = make_float4(hit.position.x, hit.position.y, hit.position.z, __uint_as_float(path));
-            b.gather[1][query] = make_float4(normal.x, normal.y, normal.z, 0.0f);
-            b.gather[2][query] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
-            b.gather[3][query] = make_float4(weight.x, weight.y, weight.z, 0.0f);
+            // waves instead of the few lanes that want it here; the caller gives it its place in the queue
+            out.wantsGather = true;
+            out.gatherPoint = v3(hit.position);
+            out.gatherNormal = normal;
+            out.gatherThroughput = throughput;
+            out.gatherWeight = weight;
         }
     }
 
@@ -554,7 +584,7 @@ __device__ inline void shadeOne(const rt_launch_params& p, const ShadeInstance* 
 __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, const ShadeInstance* instances,
                                                            const rt_hit_group_data* geometries, Buffers b, int which,
                                                            uint32_t depth) {
-    __shared__ uint32_t slots[2 * kSlotWords];
+    __shared__ uint32_t slots[3 * kSlotWords];
     const uint32_t n = b.counts[which];
     if (blockIdx.x * kShadeBlock >= n)
         return;  // whole workgroup idle
@@ -575,8 +605,18 @@ __global__ __launch_bounds__(kShadeBlock) void shadeKernel(rt_launch_params p, c
     const uint32_t shadowBits = out.shadowBits, targetInstance = out.targetInstance, targetPrimitive = out.targetPrimitive;
 
     const int next = which ^ 1;
-    uint32_t nextSlot, shadowSlot;
-    allocateSlotPair(continues, &b.counts[next], wantsShadow, &b.counts[2], slots, nextSlot, shadowSlot);
+    uint32_t nextSlot, shadowSlot, query = 0;
+    if (p.photonRadius > 0.0f)  // the same for every thread: only then can a bounce leave a photon query
+        allocateSlotTriple(continues, &b.counts[next], wantsShadow, &b.counts[2], out.wantsGather, &b.counts[3], slots, nextSlot,
+                           shadowSlot, query);
+    else
+        allocateSlotPair(continues, &b.counts[next], wantsShadow, &b.counts[2], slots, nextSlot, shadowSlot);
+    if (out.wantsGather) {
+        b.gather[0][query] = make_float4(out.gatherPoint.x, out.gatherPoint.y, out.gatherPoint.z, __uint_as_float(path));
+        b.gather[1][query] = make_float4(out.gatherNormal.x, out.gatherNormal.y, out.gatherNormal.z, 0.0f);
+        b.gather[2][query] = make_float4(out.gatherThroughput.x, out.gatherThroughput.y, out.gatherThroughput.z, 0.0f);
+        b.gather[3][query] = make_float4(out.gatherWeight.x, out.gatherWeight.y, out.gatherWeight.z, 0.0f);
+    }
     if (continues) {
         b.rayOrigin[next][nextSlot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
         b.rayDirection[next][nextSlot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
@@ -755,7 +795,6 @@ __global__ __launch_bounds__(kShadeBlock) void accumulateKernel(rt_launch_params
 // (count = perPass x passes): the passes of consecutive photon maps share one launch of every stage.
 __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_params p, uint32_t first, uint32_t count,
                                                                     uint32_t perPass, Buffers b) {
-    __shared__ uint32_t slots[kSlotWords];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     V3 origin{0, 0, 0}, direction{0, 0, 0}, power{0, 0, 0};
@@ -808,18 +847,22 @@ __global__ __launch_bounds__(kShadeBlock) void photonGenerateKernel(rt_launch_pa
             valid = maximum(power) > 0.0f;
         }
     }
+    // Every emission keeps the slot of its own index: nearly all of them carry power, and a slot drawn from the
+    // queue's counter would cost an atomic per workgroup on one word - 260,000 of them in a launch over four passes
+    // of 2^24 emissions, served one after the other (3 of the kernel's 4.3 ms).  An emission without power leaves a
+    // ray with an empty interval, which meets nothing and ends at its first bounce.
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        b.counts[0] = count;
         b.counts[1] = 0;
         b.counts[2] = 0;
     }
-    const uint32_t slot = allocateSlots(valid, &b.counts[0], slots);
-    if (valid) {
-        b.rayOrigin[0][slot] = make_float4(origin.x, origin.y, origin.z, 0.001f);
-        b.rayDirection[0][slot] = make_float4(direction.x, direction.y, direction.z, 1e16f);
-        b.rayPath[0][slot] = i;
-        b.rng[0][slot] = rng;
-        b.throughput[0][slot] = make_float4(power.x, power.y, power.z, 0.0f);
-        b.lastOrigin[0][slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0U));  // flags: bit 0 specular path, medium
+    if (i < count) {
+        b.rayOrigin[0][i] = make_float4(origin.x, origin.y, origin.z, 0.001f);
+        b.rayDirection[0][i] = make_float4(direction.x, direction.y, direction.z, valid ? 1e16f : 0.0f);
+        b.rayPath[0][i] = i;
+        b.rng[0][i] = rng;
+        b.throughput[0][i] = make_float4(power.x, power.y, power.z, 0.0f);
+        b.lastOrigin[0][i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0U));  // flags: bit 0 specular path, medium
     }
 }
 
