@@ -680,16 +680,30 @@ __global__ __launch_bounds__(kShadeBlock, RT_GATHER_WAVES) void causticGatherKer
             b.heavyQueries[base + __popcll(votes & ((1ULL << lane) - 1ULL))] = query;
         }
     }
-    // statistics: one atomic pair per wave
+    // statistics: one atomic pair per workgroup (every workgroup of a launch adds to the same two words)
+    __shared__ unsigned long long waveQueries[kShadeWaves], wavePhotons[kShadeWaves];
     unsigned long long q = finished ? 1ULL : 0ULL, g = finished ? gathered : 0U;
 #pragma unroll
     for (int delta = 32; delta >= 1; delta >>= 1) {
         q += __shfl_down(q, delta, 64);
         g += __shfl_down(g, delta, 64);
     }
-    if ((threadIdx.x & 63) == 0 && q) {
-        atomicAdd(&b.stats[2], q);
-        atomicAdd(&b.stats[3], g);
+    if ((threadIdx.x & 63) == 0) {
+        waveQueries[threadIdx.x >> 6] = q;
+        wavePhotons[threadIdx.x >> 6] = g;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q = 0;
+        g = 0;
+        for (int w = 0; w < kShadeWaves; ++w) {
+            q += waveQueries[w];
+            g += wavePhotons[w];
+        }
+        if (q) {
+            atomicAdd(&b.stats[2], q);
+            atomicAdd(&b.stats[3], g);
+        }
     }
 }
 
