@@ -14,8 +14,13 @@
 namespace rt {
 
 constexpr int kWide = 8;          // children per node
-constexpr int kFeedStride = 32;   // words between the per-XCD cursors of a persistent ray feed
-constexpr int kFeedWords = 8 * kFeedStride;
+constexpr int kFeedStride = 32;   // words between the cursors of a persistent ray feed
+#ifndef RT_FEED_SPLIT
+#define RT_FEED_SPLIT 4
+#endif
+constexpr int kFeedSplit = RT_FEED_SPLIT;  // cursors (and chunks of the index range) per XCD
+constexpr int kFeedChunks = 8 * kFeedSplit;
+constexpr int kFeedWords = kFeedChunks * kFeedStride;
 constexpr int kFeedSlots = 16;    // cursor sets a scene keeps for overlapping batched queries
 #ifndef RT_MAX_LEAF
 #define RT_MAX_LEAF 2

@@ -643,11 +643,13 @@ struct Traversal {
 };
 
 // Hands out ray indices [0, n) to the waves of a persistent launch.  The range
-// is cut into eight contiguous chunks, one per XCD (workgroups are dealt to the
-// XCDs round-robin, so blockIdx & 7 names the XCD): a wave drains the chunk of
+// is cut into contiguous chunks, kFeedSplit per XCD (workgroups are dealt to the
+// XCDs round-robin, so blockIdx & 7 names the XCD): a wave drains a chunk of
 // its own XCD first, which keeps neighbouring rays behind one L2, and then
 // helps with the others.  `cursors` holds one counter per chunk, kFeedStride
-// words apart, zeroed before the launch.
+// words apart, zeroed before the launch.  Four chunks per XCD rather than one: every draw is an atomic that
+// returns a value, those on one word are served one after the other (about 11 ns apiece), and a launch of
+// sixteen samples makes some 900,000 draws (1080p step 1.78 -> 1.74 ms).
 struct RayFeed {
     uint32_t* cursors;
     uint32_t n, chunkSize;
@@ -655,11 +657,13 @@ struct RayFeed {
     uint32_t exhausted;  // chunks found empty so far (wave-uniform)
 
     __device__ __forceinline__ RayFeed(uint32_t* c, uint32_t count) : cursors(c), n(count) {
-        chunkSize = ((count + 7U) / 8U + 63U) & ~63U;
-        chunk = blockIdx.x & 7U;
+        constexpr uint32_t chunks = kFeedChunks;
+        chunkSize = ((count + chunks - 1U) / chunks + 63U) & ~63U;
+        // the chunks of an XCD are neighbours in the index range; its workgroups start on them in turn
+        chunk = (blockIdx.x & 7U) * kFeedSplit + (blockIdx.x >> 3) % kFeedSplit;
         exhausted = 0;  // chunk and exhausted go through readfirstlane wherever they change: scalar registers
     }
-    __device__ __forceinline__ bool drained() const { return exhausted >= 8U; }
+    __device__ __forceinline__ bool drained() const { return exhausted >= static_cast<uint32_t>(kFeedChunks); }
 
     // True for a wave the launch has no use for: waves of an XCD beyond those whose
     // first draw (64 rays each) empties the XCD's chunk.  Such a wave leaves at once.
@@ -668,7 +672,7 @@ struct RayFeed {
     // atomic per chunk, that there is nothing left: atomics on one word queue up
     // behind each other, which put a floor of about 130 us under every launch.
     __device__ __forceinline__ bool surplus() const {
-        const uint32_t rank = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint32_t rank = ((blockIdx.x >> 3) / kFeedSplit) * (blockDim.x >> 6) + (threadIdx.x >> 6);
         const uint32_t begin = min(chunk * chunkSize, n), end = min(begin + chunkSize, n);
         return rank >= (end - begin + 63U) / 64U + 2U;
     }
@@ -693,7 +697,7 @@ struct RayFeed {
             return idle && mine < end;
         }
         exhausted = __builtin_amdgcn_readfirstlane(exhausted + 1U);
-        chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) & 7U);
+        chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) % kFeedChunks);
         return false;
     }
 
@@ -701,7 +705,7 @@ struct RayFeed {
     // a ray).  Returns true with `index` set for the lanes that got one.
     __device__ __forceinline__ bool take(unsigned long long idleMask, bool idle, uint32_t& index) {
         const int lane = threadIdx.x & 63;
-        while (exhausted < 8U) {
+        while (exhausted < static_cast<uint32_t>(kFeedChunks)) {
             const uint32_t begin = min(chunk * chunkSize, n), end = min(begin + chunkSize, n);
             const uint32_t want = __popcll(idleMask);
             uint32_t base = 0;
@@ -714,7 +718,7 @@ struct RayFeed {
                 return idle && mine < end;
             }
             exhausted = __builtin_amdgcn_readfirstlane(exhausted + 1U);
-            chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) & 7U);
+            chunk = __builtin_amdgcn_readfirstlane((chunk + 1U) % kFeedChunks);
         }
         return false;
     }
