@@ -713,6 +713,7 @@ __global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launc
     const uint32_t n = b.counts[4];
     const uint32_t waves = gridDim.x * (kShadeBlock / 64);
     const uint32_t lane = threadIdx.x & 63U;
+    unsigned long long queries = 0, photons = 0;  // of this wave, for the statistics (lane 0 counts)
     for (uint32_t item = blockIdx.x * (kShadeBlock / 64) + (threadIdx.x >> 6); item < n; item += waves) {
         const uint32_t query = b.heavyQueries[item];
         const float4 point = b.gather[0][query];
@@ -729,9 +730,13 @@ __global__ __launch_bounds__(kShadeBlock) void causticGatherHeavyKernel(rt_launc
             const V3 caustic = rgb(b.gather[3][query]) * V3{fx, fy, fz};
             const V3 sum = rgb(b.sample[3][path]) + rgb(b.gather[2][query]) * caustic;
             b.sample[3][path] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-            atomicAdd(&b.stats[2], 1ULL);
-            atomicAdd(&b.stats[3], static_cast<unsigned long long>(gathered));
+            ++queries;
+            photons += gathered;
         }
+    }
+    if (lane == 0U && queries) {
+        atomicAdd(&b.stats[2], queries);
+        atomicAdd(&b.stats[3], photons);
     }
 }
 
