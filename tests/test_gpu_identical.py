@@ -132,6 +132,45 @@ def test_caustic_lab_with_its_photon_maps(R, oracle):
     assert_identical(buffers_of(R, r, w * h), host.aov, "caustic-lab, final profile")
 
 
+def test_photon_lists_of_several_kinds_of_light(R, oracle):
+    """The photon tracer over a light list with a spot, a point and a directional light, an emissive panel and a light
+    of no intensity (it is drawn with its share of the emissions, which then carry no power and must leave nothing):
+    two passes, photon by photon."""
+    scene = workloads.caustic_lab()
+    inf = float("inf")
+    scene["lights"] += [
+        dict(transform=workloads.translation(-0.5, 1.2, 0.6), color=(0.3, 0.6, 1.0), intensity=4.0,
+             range=inf, innerCone=0.0, outerCone=0.7853982, type=2),
+        dict(transform=workloads.translation(0.0, 1.0, 0.0), color=(1.0, 1.0, 1.0), intensity=0.0,
+             range=inf, innerCone=0.0, outerCone=0.7853982, type=2),
+        dict(transform=workloads.look_at([0.2, 1.9, 0.9], [0.0, 0.0, -0.2]), color=(1.0, 1.0, 0.8), intensity=0.8,
+             range=inf, innerCone=0.0, outerCone=0.7853982, type=0),
+    ]
+    panel = workloads.quad([-0.2, 1.4, -0.2], [0.2, 1.4, -0.2], [0.2, 1.4, 0.2], [-0.2, 1.4, 0.2])
+    scene["materials"].append(workloads.default_material(baseColor=(0, 0, 0, 1), emissive=(1.0, 0.9, 0.7), emissiveStrength=6.0))
+    scene["geometries"].append({"vertices": panel[0], "indices": panel[1], "material": len(scene["materials"]) - 1})
+    scene["instances"].append((len(scene["geometries"]) - 1, np.eye(4, dtype=np.float32).reshape(-1)))
+    budget = (1 << 18, 1 << 17, 1 << 15)
+    r = R.Renderer(scene, 64, 36, 1)
+    r.set_photon_budget(*budget)
+    r.set_manual_photon_passes(True)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    assert host.params.lightCount >= 5
+    host.params.photonRadius = r.caustic_radius()
+    for k in range(2):
+        r.begin_photon_pass()
+        stored = r.trace_photon_range(0, budget[0])
+        gpu_photons = R.device_to_host(r.photon_buffer(), stored * 36).view(np.float32).reshape(-1, 9).copy()
+        r.finish_photon_pass(stored)
+        host.params.photonPass = k
+        ph, wanted = ref.trace_photons(host.params, 0, budget[0], budget[1], threads=16)
+        assert wanted == stored and stored > 500
+        assert np.array_equal(gpu_photons.view(np.uint32), ph.view(np.uint32)), f"photon list of pass {k}"
+        for _ in range(4):
+            r.render()
+
+
 @pytest.mark.parametrize("which", ["sky", "maps"])
 def test_textured_scenes(R, oracle, which):
     """Texture lookups with transforms (a rotation: sine and cosine), sRGB decoding (power 2.4), the environment
