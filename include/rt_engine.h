@@ -250,15 +250,17 @@ rt_status rt_trace_closest_counted(const rt_scene* scene, const rt_float4* origi
 typedef struct rt_wavefront rt_wavefront; /* ray queues and per-path state for up to maxPaths paths */
 rt_status rt_wavefront_create(uint32_t maxPaths, rt_wavefront** out);
 void rt_wavefront_destroy(rt_wavefront* wavefront);
-/* A state for one kind of pass only leaves out the arrays the other kind needs
+/* A state for one kind of pass only leaves out the arrays the other kinds need
  * (a camera pass has no use for the per-emission photon slots, a photon pass
- * none for shadow rays, sample sums and photon queries); rt_wavefront_create
- * is both.  rt_wavefront_state_bytes: the device memory such a state takes,
+ * none for shadow rays, sample sums and photon queries, a camera pass that
+ * never reads a photon map none for the query queues and the caustic sum:
+ * 84 of its 356 bytes per path); rt_wavefront_create is all of them.  rt_wavefront_state_bytes: the device memory such a state takes,
  * from the same list of arrays the allocation walks - what a caller sizes a
  * pass against free memory with.  No counterpart upstream (OptiX keeps the
  * state of a launch in its own stack and registers). */
-#define RT_WAVEFRONT_FOR_CAMERA 1u  /* rt_render_sample* */
+#define RT_WAVEFRONT_FOR_CAMERA 1u  /* rt_render_sample*, with or without a photon map */
 #define RT_WAVEFRONT_FOR_PHOTONS 2u /* rt_trace_photons */
+#define RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS 4u /* rt_render_sample* with params->photonRadius == 0 only */
 rt_status rt_wavefront_create_for(uint32_t maxPaths, uint32_t uses, rt_wavefront** out);
 rt_status rt_wavefront_state_bytes(uint32_t maxPaths, uint32_t uses, size_t* bytes);
 

@@ -1048,9 +1048,13 @@ namespace {
 
 // Every device array of a wavefront state in one place: `visit(pointer, count, uses)` is called once per
 // array with the kinds of pass that need it, so the allocation and the size query cannot drift apart.
+constexpr uint32_t kAllUses = RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS | RT_WAVEFRONT_FOR_PHOTONS;
+
 template <typename Visit>
 void forEachArray(rt_wavefront& w, size_t maxPaths, Visit&& visit) {
-    constexpr uint32_t camera = RT_WAVEFRONT_FOR_CAMERA, photons = RT_WAVEFRONT_FOR_PHOTONS, both = camera | photons;
+    // `gathers`: camera passes that read a photon map; `camera`: those and the ones that never do
+    constexpr uint32_t gathers = RT_WAVEFRONT_FOR_CAMERA, camera = gathers | RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS;
+    constexpr uint32_t photons = RT_WAVEFRONT_FOR_PHOTONS, both = camera | photons;
     Buffers& b = w.buffers;
     for (int k = 0; k < 2; ++k) {
         visit(b.rayOrigin[k], maxPaths, both);
@@ -1071,10 +1075,10 @@ void forEachArray(rt_wavefront& w, size_t maxPaths, Visit&& visit) {
     }
     for (int k = 0; k < 6; ++k)
         if (k != 1 && k != 2)
-            visit(b.sample[k], maxPaths, camera);
+            visit(b.sample[k], maxPaths, k == 3 ? gathers : camera);  // 3: the caustic sum
     for (int k = 0; k < 4; ++k)
-        visit(b.gather[k], maxPaths, camera);
-    visit(b.heavyQueries, maxPaths, camera);
+        visit(b.gather[k], maxPaths, gathers);
+    visit(b.heavyQueries, maxPaths, gathers);
     visit(b.counts, size_t{8}, both);
     visit(b.feed, static_cast<size_t>(kFeedWords), both);
     visit(b.stats, size_t{8}, both);
@@ -1105,8 +1109,8 @@ void rt_wavefront_destroy(rt_wavefront* w) {
 rt_status rt_wavefront_state_bytes(uint32_t maxPaths, uint32_t uses, size_t* bytes) {
     if (!bytes)
         return failInvalid("bytes is null");
-    if (uses == 0 || (uses & ~(RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS)))
-        return failInvalid("uses: RT_WAVEFRONT_FOR_CAMERA and / or RT_WAVEFRONT_FOR_PHOTONS");
+    if (uses == 0 || (uses & ~kAllUses))
+        return failInvalid("uses: a sum of RT_WAVEFRONT_FOR_CAMERA, _CAMERA_NO_CAUSTICS and _PHOTONS");
     rt_wavefront scratch;
     size_t total = 0;
     forEachArray(scratch, maxPaths, [&](auto*& pointer, size_t count, uint32_t neededBy) {
@@ -1124,8 +1128,8 @@ rt_status rt_wavefront_create_for(uint32_t maxPaths, uint32_t uses, rt_wavefront
     *out = nullptr;
     if (maxPaths == 0)
         return failInvalid("maxPaths is zero");
-    if (uses == 0 || (uses & ~(RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_PHOTONS)))
-        return failInvalid("uses: RT_WAVEFRONT_FOR_CAMERA and / or RT_WAVEFRONT_FOR_PHOTONS");
+    if (uses == 0 || (uses & ~kAllUses))
+        return failInvalid("uses: a sum of RT_WAVEFRONT_FOR_CAMERA, _CAMERA_NO_CAUSTICS and _PHOTONS");
     auto* w = new rt_wavefront();
     w->uses = uses;
     RT_HIP(hipGetDevice(&w->device));
@@ -1398,8 +1402,10 @@ static rt_status renderPaths(rt_wavefront* w, const rt_launch_params* params, co
     map.count = map.perSample * map.samples;
     const uint32_t count = map.count;
     const Buffers b = buffersFor(w, params);
-    if (!(w->uses & RT_WAVEFRONT_FOR_CAMERA))
+    if (!(w->uses & (RT_WAVEFRONT_FOR_CAMERA | RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS)))
         return failInvalid("this wavefront state was created for photon passes only");
+    if (!(w->uses & RT_WAVEFRONT_FOR_CAMERA) && params->photonRadius > 0.0f)
+        return failInvalid("this wavefront state was created without the photon-query arrays: photonRadius must be 0");
     PhotonMaps photonMaps = w->photonMaps;
     photonMaps.perSample = map.perSample;
     const unsigned blocks = divUp(count, kShadeBlock);

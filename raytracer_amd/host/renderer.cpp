@@ -427,6 +427,7 @@ struct Renderer::Impl {
     std::uint64_t photonWavefrontAsked = 0;  // paths the state was last sized for, before the memory budget cut them
     float gatherRadius = 0.0f;
     bool caustics = false;
+    bool partsGather = false;  // the camera states of `parts` have the arrays a gather needs
     bool overflowReported = false;
     // The stored count of a pass stays on the device; a copy of it travels to pinned host memory behind the
     // pass and is looked at when it has arrived (reportOverflow), for the reference's warning.
@@ -1152,9 +1153,14 @@ struct Renderer::Impl {
 
     void ensureParts() {
         const std::uint64_t needed = neededCapacity();
-        if (parts.empty() || needed > partCapacity || needed * 2U < partCapacity)
+        if (parts.empty() || needed > partCapacity || needed * 2U < partCapacity || (gatherWanted() && !partsGather))
             createParts(needed);
     }
+
+    // Camera states carry the photon-query queues and the caustic sum only where a pass can gather: with the
+    // final profile, or after a driver started a photon pass by hand in another.
+    bool gatherWanted() const { return caustics || launch.photonRadius > 0.0f; }
+    std::uint32_t cameraUses() const { return partsGather ? RT_WAVEFRONT_FOR_CAMERA : RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS; }
 
     void dropParts() {
         hipOk(hipDeviceSynchronize());
@@ -1167,6 +1173,7 @@ struct Renderer::Impl {
         destroyParts();
         const std::uint32_t count = partCount;
         partCapacity = capacity;
+        partsGather = gatherWanted();
         // Passes in flight: what was asked for, else two - with passes of several samples a second pass is
         // enough to cover the end of the first, and the state it saves goes into larger passes (1080p: 16 x 2
         // 1.95 ms per sample, 8 x 4 1.99).
@@ -1210,10 +1217,10 @@ struct Renderer::Impl {
     }
 
     // Device bytes of a camera state of `paths` paths, as the engine states them.
-    static std::uint64_t stateBytes(std::uint64_t paths) {
+    std::uint64_t stateBytes(std::uint64_t paths) const {
         std::size_t bytes = 0;
         engineOk(rt_wavefront_state_bytes(static_cast<std::uint32_t>(std::min<std::uint64_t>(paths, 0xffffffffULL)),
-                                          RT_WAVEFRONT_FOR_CAMERA, &bytes),
+                                          cameraUses(), &bytes),
                  "rt_wavefront_state_bytes");
         return bytes;
     }
@@ -1225,7 +1232,7 @@ struct Renderer::Impl {
         for (Part& part : parts) {
             if (capacity * batch > 0xffffffffULL)
                 raise("sample batch: pixels x samples of a pass do not fit 32 bits");
-            engineOk(rt_wavefront_create_for(static_cast<std::uint32_t>(capacity * batch), RT_WAVEFRONT_FOR_CAMERA, &part.wavefront),
+            engineOk(rt_wavefront_create_for(static_cast<std::uint32_t>(capacity * batch), cameraUses(), &part.wavefront),
                      "rt_wavefront_create_for");
             engineOk(rt_wavefront_configure(part.wavefront, measurementFlags), "rt_wavefront_configure");
             // a single part stays on the default stream; parts that run side by side take half the wave

@@ -311,6 +311,65 @@ def test_sample_launch_through_the_c_abi(R, engine):
         lib.rt_wavefront_destroy(state)
 
 
+def test_camera_state_without_the_photon_query_arrays(R, engine):
+    """A state created with RT_WAVEFRONT_FOR_CAMERA_NO_CAUSTICS leaves out the four query arrays, the heavy-query
+    list and the caustic sum (84 bytes a path), renders a sample without a photon map bit for bit as a full state
+    does, and refuses launch parameters with a gather radius.  The Renderer takes such states in its preview
+    profile and full ones in the final profile."""
+    import ctypes as C
+    import torch
+    lib = engine.load()
+    camera, photons, plain = 1, 2, 4
+    paths = 1 << 20
+    sizes = {}
+    for uses in (camera, photons, plain, camera | plain, camera | photons, camera | photons | plain):
+        n = C.c_size_t(0)
+        engine.check(lib.rt_wavefront_state_bytes(paths, uses, C.byref(n)))
+        sizes[uses] = n.value
+    assert sizes[camera] - sizes[plain] == 84 * paths
+    assert sizes[camera | plain] == sizes[camera] and sizes[camera | photons | plain] == sizes[camera | photons]
+    for uses in (0, 8, 15):
+        with pytest.raises(engine.EngineError, match="uses"):
+            engine.check(lib.rt_wavefront_state_bytes(paths, uses, C.byref(C.c_size_t(0))))
+    w, h = 48, 27
+    r = R.Renderer(workloads.caustic_lab(), w, h, R.PREVIEW)
+    r.set_concurrent_tiles(1)
+    r.render()
+    r.synchronize()
+    first = [R.device_to_host(r.accumulation_buffer(k), w * h * 16).copy() for k in range(7)]
+    state = C.c_void_p(0)
+    engine.check(lib.rt_wavefront_create_for(w * h, plain, C.byref(state)))
+    try:
+        params = r.launch_params()
+        params.sample = 0
+        assert params.photonRadius == 0.0
+        engine.check(lib.rt_render_sample(state, C.byref(params), 0, w * h, None))
+        torch.cuda.synchronize()
+        for k in range(7):
+            assert np.array_equal(first[k], R.device_to_host(r.accumulation_buffer(k), w * h * 16)), k
+        with_map = R.LaunchParams.from_buffer_copy(params)
+        with_map.photonRadius = 0.01
+        with pytest.raises(engine.EngineError, match="photonRadius"):
+            engine.check(lib.rt_render_sample(state, C.byref(with_map), 0, w * h, None))
+    finally:
+        lib.rt_wavefront_destroy(state)
+    # the same renderer in the final profile: its states grow by the arrays of the gather, and a photon pass
+    # started by hand in the preview profile gets them as well
+    r.set_profile(R.FINAL)
+    r.render()
+    r.synchronize()
+    assert r.statistics()["gather_queries"] > 0
+    r.set_profile(R.PREVIEW)
+    r.render()
+    r.synchronize()
+    r.begin_photon_pass()
+    stored = r.trace_photon_range(0, r.photon_emissions())
+    r.finish_photon_pass(stored)
+    r.render()
+    r.synchronize()
+    assert r.statistics()["gather_queries"] > 0
+
+
 def test_tiny_photon_budgets(R, oracle):
     """Photon budgets at the lower end: one bucket (every neighbour cell is the same bucket), two buckets,
     a capacity of one photon (the buffer overflows and the map keeps what fits), one emission.  The
