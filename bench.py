@@ -289,6 +289,8 @@ def run_workload(args, workload, steps, warmup, world, rank, wire):
             renderer.set_photon_budget(*budget)
         if args.batch:
             renderer.set_sample_batch(args.batch)
+        if os.environ.get("RT_BENCH_RAY_SHARE"):  # development aid: "4/5" leaves a fifth of the wave slots to other launches
+            renderer.set_ray_share(*(int(x) for x in os.environ["RT_BENCH_RAY_SHARE"].split("/")))
         step = renderer.render
 
     # traversal averages per ray (for the algorithmic byte count), outside the timed region
