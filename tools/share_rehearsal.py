@@ -21,6 +21,7 @@ ap.add_argument("--workload", default="dragon-cornell", choices=["dragon-cornell
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--in-flight", type=int, default=0)
 ap.add_argument("--steps", type=int, default=128)
+ap.add_argument("--warmup", type=int, default=64)
 args = ap.parse_args()
 R.load()
 final = args.workload == "caustic-lab"
@@ -51,7 +52,7 @@ for share in args.shares:
             r.finish_photon_passes(full[:passes])
         r.render()
 
-    for _ in range(64):
+    for _ in range(args.warmup):
         step()
     r.synchronize()
     t0 = time.perf_counter()
