@@ -353,6 +353,13 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
+/* Enqueues an empty ray launch of this state on `stream`.  The ray kernels keep
+ * the deep end of their traversal stacks in private memory, and the first
+ * launch of such a kernel on a hardware queue waits for that queue's scratch
+ * memory to be set up (about 130 us on an MI355X, once per queue and process):
+ * a caller that creates its streams ahead of time pays for it there instead of
+ * in the middle of its first pass on each of them.  No counterpart upstream. */
+rt_status rt_wavefront_prepare_stream(rt_wavefront* wavefront, void* stream);
 /* Later rt_render_sample* calls on this state render `samples` consecutive
  * samples of their pixels in one pass: sample params->sample + k is seeded
  * with seedSample + k * seedStride, k < samples, and the samples enter the

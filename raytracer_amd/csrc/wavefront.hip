@@ -1201,6 +1201,21 @@ rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32
     return RT_SUCCESS;
 }
 
+rt_status rt_wavefront_prepare_stream(rt_wavefront* w, void* stream) {
+    if (!w)
+        return failInvalid("null pointer");
+    auto s = static_cast<hipStream_t>(stream);
+    const Buffers& b = w->buffers;
+    // the grid of a full launch (the scratch of a queue is sized by the launch that asks for it), no rays: every wave
+    // finds the feed empty and leaves
+    RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
+    hipLaunchKernelGGL(traceKernel<false>, dim3(persistentBlocks(w->device)), dim3(kTraceBlock), 0, s,
+                       static_cast<const WideNode*>(nullptr), static_cast<const InstanceRecord*>(nullptr), b, -1, 0,
+                       make_uint2(0U, 0U));
+    RT_HIP(hipGetLastError());
+    return RT_SUCCESS;
+}
+
 rt_status rt_wavefront_set_sample_batch(rt_wavefront* w, uint32_t samples, uint32_t seedStride) {
     if (!w)
         return failInvalid("null pointer");

@@ -82,6 +82,7 @@ SYMBOLS = {
     "rt_wavefront_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, _vp]),
     "rt_wavefront_configure": (C.c_int, [_vp, _u32]),
     "rt_wavefront_set_ray_share": (C.c_int, [_vp, _u32, _u32]),
+    "rt_wavefront_prepare_stream": (C.c_int, [_vp, _vp]),
     "rt_wavefront_set_bucket_bitmap": (C.c_int, [_vp, _vp]),
     "rt_light_index_bytes": (C.c_int, [_u32, C.POINTER(C.c_size_t)]),
     "rt_light_index_build": (C.c_int, [_vp, _u32, _vp, C.c_size_t, _vp]),

@@ -900,6 +900,7 @@ struct Renderer::Impl {
         engineOk(rt_wavefront_create_for(static_cast<std::uint32_t>(wanted), RT_WAVEFRONT_FOR_PHOTONS, &photonWavefront),
                  "rt_wavefront_create_for");
         engineOk(rt_wavefront_set_light_index(photonWavefront, lightIndex, launch.lightCount), "rt_wavefront_set_light_index");
+        engineOk(rt_wavefront_prepare_stream(photonWavefront, photonStream), "rt_wavefront_prepare_stream");
         photonWavefrontCapacity = static_cast<std::uint32_t>(wanted);
     }
 
@@ -1245,6 +1246,8 @@ struct Renderer::Impl {
                 engineOk(rt_wavefront_set_ray_share(part.wavefront, 1, 2), "rt_wavefront_set_ray_share");
             if (depth > 1)
                 hipOk(hipEventCreateWithFlags(&part.accumulated, hipEventDisableTiming));
+            // the stream's hardware queue sets up scratch memory for the ray kernels now, not in its first pass
+            engineOk(rt_wavefront_prepare_stream(part.wavefront, part.stream), "rt_wavefront_prepare_stream");
         }
     }
 
