@@ -353,7 +353,8 @@ rt_status rt_wavefront_configure(rt_wavefront* wavefront, uint32_t flags);
  * splits a frame (no counterpart upstream: the reference renders a frame
  * with one launch, renderer.cpp:779-796). */
 rt_status rt_wavefront_set_ray_share(rt_wavefront* wavefront, uint32_t numerator, uint32_t denominator);
-/* Enqueues an empty ray launch of this state on `stream`.  The ray kernels keep
+/* Enqueues an empty launch with the private segment and the grid of this
+ * state's ray launches on `stream`.  The ray kernels keep
  * the deep end of their traversal stacks in private memory, and the first
  * launch of such a kernel on a hardware queue waits for that queue's scratch
  * memory to be set up (about 130 us on an MI355X, once per queue and process):

@@ -1015,6 +1015,21 @@ __global__ void photonCountKernel(uint32_t perPass, uint32_t passes, const uint3
         *lists.counter[pass] += offsets[(pass + 1U) * perPass] - offsets[pass * perPass];
 }
 
+// A kernel with the private segment of the ray kernels and nothing to do (rounds == 0): launched once on a stream,
+// it makes the stream's hardware queue set up its scratch memory ahead of the first ray launch.  1 KiB per lane covers
+// the 928 to 960 bytes the ray kernels take for the deep end of their stacks.
+__global__ __launch_bounds__(kTraceBlock) void scratchSetupKernel(uint32_t* sink, uint32_t rounds) {
+    uint32_t spill[256];
+    if (rounds == 0U)
+        return;
+    for (uint32_t i = 0; i < 256U; ++i)
+        spill[(i * 7U + threadIdx.x) & 255U] = i;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < rounds; ++i)
+        sum += spill[(sum + i) & 255U];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 }  // namespace
 }  // namespace rt
 
@@ -1204,14 +1219,9 @@ rt_status rt_wavefront_set_ray_share(rt_wavefront* w, uint32_t numerator, uint32
 rt_status rt_wavefront_prepare_stream(rt_wavefront* w, void* stream) {
     if (!w)
         return failInvalid("null pointer");
-    auto s = static_cast<hipStream_t>(stream);
-    const Buffers& b = w->buffers;
-    // the grid of a full launch (the scratch of a queue is sized by the launch that asks for it), no rays: every wave
-    // finds the feed empty and leaves
-    RT_HIP(hipMemsetAsync(b.feed, 0, sizeof(uint32_t) * kFeedWords, s));
-    hipLaunchKernelGGL(traceKernel<false>, dim3(persistentBlocks(w->device)), dim3(kTraceBlock), 0, s,
-                       static_cast<const WideNode*>(nullptr), static_cast<const InstanceRecord*>(nullptr), b, -1, 0,
-                       make_uint2(0U, 0U));
+    // the grid of a full ray launch: the scratch memory of a queue is sized by the launch that asks for it
+    hipLaunchKernelGGL(scratchSetupKernel, dim3(persistentBlocks(w->device)), dim3(kTraceBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint32_t*>(nullptr), 0U);
     RT_HIP(hipGetLastError());
     return RT_SUCCESS;
 }

@@ -343,7 +343,7 @@ def test_camera_state_without_the_photon_query_arrays(R, engine):
         params = r.launch_params()
         params.sample = 0
         assert params.photonRadius == 0.0
-        # an empty ray launch ahead of the first pass (the queue's scratch set-up) changes nothing
+        # an empty launch ahead of the first pass (the queue's scratch set-up) changes nothing
         engine.check(lib.rt_wavefront_prepare_stream(state, None))
         engine.check(lib.rt_render_sample(state, C.byref(params), 0, w * h, None))
         torch.cuda.synchronize()
