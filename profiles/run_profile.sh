@@ -9,8 +9,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 sha256sum raytracer_amd/librt_engine.so > $OUT/library.sha256
 export TMPDIR=/tmp
-# one region, one pass in flight: a launch overlaps no other, so its span is its own; passes of eight samples, as the default bench renders a 1080p frame
-BENCH="python3 bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-extra-legs --tiles 1 --in-flight 1 --batch 16"
+# one region, one pass in flight, passes of 32 samples: as the default bench renders a 1080p frame
+BENCH="python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --no-extra-legs --tiles 1 --in-flight 1 --batch 32"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1

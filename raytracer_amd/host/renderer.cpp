@@ -1177,7 +1177,7 @@ struct Renderer::Impl {
         partsGather = gatherWanted();
         // Passes in flight: what was asked for, else two - with passes of several samples a second pass is
         // enough to cover the end of the first, and the state it saves goes into larger passes (1080p: 16 x 2
-        // 1.95 ms per sample, 8 x 4 1.99).
+        // 1.95 ms per sample, 8 x 4 1.99) - or one, see below.
         depth = depthWanted ? depthWanted : 2U;
         // Samples per pass: what was asked for, else the most of 64, 32, ..., 1 whose state fits the budget - the
         // lesser of kStateBudget and half of the device memory that is free now, priced with the engine's own
@@ -1197,6 +1197,14 @@ struct Renderer::Impl {
             const std::uint64_t photonBudget = std::min<std::uint64_t>(16ULL << 30, freeBytes / 4U);
             while (caustics && batch > kPhotonRebuildInterval && photonPoolBytes(batch) > photonBudget)
                 batch /= 2;
+            // Without a photon map a larger pass beats a second pass in flight (1080p: 32 x 1 1.65 ms per sample, 16 x 2
+            // 1.69, 16 x 1 1.70): where two passes of the full 64 samples do not fit, the memory of the second goes
+            // into one pass of twice the samples.  With a photon map the second pass stays: the photon passes of the
+            // next camera pass run beside the current one (32 x 1 2.19 ms per sample, 16 x 2 2.01).
+            if (!depthWanted && !caustics && batch < 64U && stateBytes(capacity * batch * 2U) * count <= budget) {
+                batch *= 2U;
+                depth = 1U;
+            }
         }
         for (;;) {
             try {
@@ -1471,7 +1479,11 @@ void Renderer::setRayShare(std::uint32_t numerator, std::uint32_t denominator) {
 }
 
 std::uint32_t Renderer::concurrentTiles() const { return impl_->partCount; }
-std::uint32_t Renderer::samplesInFlight() const { return impl_->depthWanted ? impl_->depthWanted : 2U; }
+std::uint32_t Renderer::samplesInFlight() const {
+    impl_->flush();
+    impl_->ensureParts();
+    return impl_->depth;
+}
 void Renderer::synchronize() const {
     impl_->flush();
     hipOk(hipDeviceSynchronize());

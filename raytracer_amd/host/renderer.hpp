@@ -62,8 +62,9 @@ public:
     // on a stream of its own, their accumulation steps chained in sample order: for small frames or
     // small shares of one, where a single sample's launches cannot fill the GPU.  Restarts the
     // accumulation.
-    // samplesInFlight 0 leaves the choice to the renderer: two passes in flight.  The default is one region
-    // and that choice.
+    // samplesInFlight 0 leaves the choice to the renderer: two passes in flight, or - without a photon map, where
+    // two passes of 64 samples do not fit the state budget - one pass of twice the samples.  The default is one
+    // region and that choice; samplesInFlight() is what is in use.
     void setConcurrentTiles(std::uint32_t count, std::uint32_t samplesInFlight = 1);
     std::uint32_t samplesInFlight() const;
     // render() calls are collected into passes of up to `samples` consecutive samples (1 to 64) that the GPU

@@ -528,7 +528,7 @@ def test_concurrent_tiles_do_not_change_the_image(R):
     w, h = 64, 72
     images = []
     default = R.Renderer(scene, w, h)
-    # the renderer's own choice: two passes in flight, four with the final profile (single-sample passes)
+    # the renderer's own choice: two passes in flight (a frame this small has room for two passes of 64 samples)
     assert (default.concurrent_tiles(), default.samples_in_flight()) == (1, 2)
     assert R.Renderer(scene, w, h, R.FINAL).samples_in_flight() == 2
     default.set_concurrent_tiles(1, 3)
