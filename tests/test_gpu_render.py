@@ -372,6 +372,29 @@ def test_camera_state_without_the_photon_query_arrays(R, engine):
     assert r.statistics()["gather_queries"] > 0
 
 
+def test_default_schedule_follows_the_state_budget(R):
+    """What the renderer picks by itself on a GPU with memory to spare: the most samples per pass (64 at most) whose
+    state fits 24 GiB; two passes in flight where two passes of 64 samples fit (a quarter of a 1080p frame), else -
+    without a photon map - one pass of twice the samples (the whole frame: 32 x 1, half of it: 64 x 1); with a
+    photon map two passes stay (16 x 2, four photon passes traced together)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < (80 << 30):
+        pytest.skip("the defaults are cut to half of the free memory; this test states them for a free GPU")
+    scene = workloads.cornell_box()
+    for shares, expected in ((1, (32, 1)), (2, (64, 1)), (4, (64, 2)), (8, (64, 2))):
+        r = R.Renderer(scene, 1920, 1080, R.PREVIEW)
+        r.set_row_interleave(0, shares)   # the state is made for the share, with the first question about it
+        assert (r.sample_batch(), r.samples_in_flight()) == expected, shares
+        del r
+    r = R.Renderer(scene, 1920, 1080, R.PREVIEW)
+    r.set_concurrent_tiles(1, 2)   # a number the caller names is kept
+    assert (r.sample_batch(), r.samples_in_flight()) == (16, 2)
+    del r
+    final = R.Renderer(workloads.caustic_lab(), 1920, 1080, R.FINAL)
+    assert (final.sample_batch(), final.samples_in_flight(), final.photon_passes_together()) == (16, 2, 4)
+
+
 def test_tiny_photon_budgets(R, oracle):
     """Photon budgets at the lower end: one bucket (every neighbour cell is the same bucket), two buckets,
     a capacity of one photon (the buffer overflows and the map keeps what fits), one emission.  The
