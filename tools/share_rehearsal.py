@@ -22,6 +22,7 @@ ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--in-flight", type=int, default=0)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--warmup", type=int, default=64)
+ap.add_argument("--ray-share", default="", help="N/D: the share of the wave slots a ray launch takes")
 args = ap.parse_args()
 R.load()
 final = args.workload == "caustic-lab"
@@ -35,6 +36,8 @@ for share in args.shares:
         r.set_sample_batch(args.batch)
     if args.in_flight:
         r.set_concurrent_tiles(1, args.in_flight)
+    if args.ray_share:
+        r.set_ray_share(*(int(x) for x in args.ray_share.split("/")))
     r.set_row_interleave(0, share)
     full = []
     if final and share > 1:
