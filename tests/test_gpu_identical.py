@@ -87,6 +87,28 @@ def test_dragon_cornell(R, oracle):
     assert_identical(buffers_of(R, r, w * h), host.aov, "dragon-cornell stand-in")
 
 
+def test_dragon_cornell_at_the_size_the_benchmark_renders(R, oracle):
+    """1920 x 1080, the frame configuration 2 names: 40 rows through the middle of the mesh (76,800 pixels, what
+    the oracle walks in seconds), three samples in one pass of the renderer at its defaults for that frame."""
+    scene = workloads.dragon_cornell()
+    w, h = 1920, 1080
+    begin, end = 520 * w, 560 * w
+    r = R.Renderer(scene, w, h, 0)
+    r.set_pixel_range(begin, end)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    for s in range(3):
+        r.render()
+        host.params.sample = s
+        ref.render_sample(host.params, begin, end, 16)
+    r.synchronize()
+    gpu = buffers_of(R, r, w * h)
+    assert host.aov[3][begin:end, :3].sum() > 0 and host.aov[0][begin:end, :3].mean() > 0.01
+    assert_identical([g[begin:end] for g in gpu], [c[begin:end] for c in host.aov], "dragon-cornell rows at 1080p")
+    stats = r.statistics()
+    assert stats["extend_rays"] > 3 * (end - begin) and stats["refused_references"] == 0
+
+
 def test_sphere_field(R, oracle):
     """Environment map with importance sampling (arc tangent and arc cosine per lookup, sine per density),
     directional light, thin lens, 504 instances, rough metal and clear glass."""
@@ -130,6 +152,44 @@ def test_caustic_lab_with_its_photon_maps(R, oracle):
     r.synchronize()
     assert host.aov[4][:, :3].sum() > 0
     assert_identical(buffers_of(R, r, w * h), host.aov, "caustic-lab, final profile")
+
+
+def test_caustic_lab_at_the_reference_sizes(R, oracle):
+    """Configuration 3 as it is named: 1920 x 1080, final profile, 2^24 emissions into at most 2^23 photons over 2^22
+    buckets.  The whole photon list of the first pass, photon by photon, and two samples of 24 rows across the table
+    that gather from it."""
+    scene = workloads.caustic_lab()
+    w, h = 1920, 1080
+    budget = (1 << 24, 1 << 23, 1 << 22)
+    begin, end = 380 * w, 404 * w
+    r = R.Renderer(scene, w, h, 1)
+    r.set_photon_budget(*budget)
+    r.set_manual_photon_passes(True)
+    r.set_pixel_range(begin, end)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    radius = r.caustic_radius()
+    assert r.photon_pass_due()
+    r.begin_photon_pass()
+    stored = r.trace_photon_range(0, budget[0])
+    gpu_photons = R.device_to_host(r.photon_buffer(), stored * 36).view(np.float32).reshape(-1, 9).copy()
+    r.finish_photon_pass(stored)
+    host.params.photonRadius = radius
+    host.params.photonPass = 0
+    ph, wanted = ref.trace_photons(host.params, 0, budget[0], budget[1], threads=16)
+    assert wanted == stored and stored > 500000
+    assert np.array_equal(gpu_photons.view(np.uint32), ph.view(np.uint32)), "photon list at the reference sizes"
+    offsets, srt = oracle.build_photon_grid(ph, radius, budget[2])
+    host.sorted[: len(srt)] = srt
+    host.cell_start[:] = offsets
+    for s in range(2):
+        r.render()
+        host.params.sample = s
+        ref.render_sample(host.params, begin, end, 16)
+    r.synchronize()
+    gpu = buffers_of(R, r, w * h)
+    assert host.aov[4][begin:end, :3].sum() > 0
+    assert_identical([g[begin:end] for g in gpu], [c[begin:end] for c in host.aov], "caustic-lab rows at 1080p")
 
 
 def test_photon_lists_of_several_kinds_of_light(R, oracle):
