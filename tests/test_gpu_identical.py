@@ -119,6 +119,26 @@ def test_sphere_field(R, oracle):
     assert_identical(buffers_of(R, r, w * h), host.aov, "sphere field")
 
 
+def test_sphere_field_at_the_size_configuration_4_names(R, oracle):
+    """3840 x 2160: 16 rows through the spheres (61,440 pixels), two samples - environment light, thin lens, 504
+    instances."""
+    scene = workloads.sphere_field(sky=True)
+    w, h = 3840, 2160
+    begin, end = 1200 * w, 1216 * w
+    r = R.Renderer(scene, w, h, 0)
+    r.set_pixel_range(begin, end)
+    ref = oracle_scene(oracle, scene)
+    host = HostParams(r, scene)
+    for s in range(2):
+        r.render()
+        host.params.sample = s
+        ref.render_sample(host.params, begin, end, 16)
+    r.synchronize()
+    gpu = buffers_of(R, r, w * h)
+    assert host.aov[0][begin:end, :3].mean() > 0.05 and host.aov[2][begin:end, :3].sum() > 0
+    assert_identical([g[begin:end] for g in gpu], [c[begin:end] for c in host.aov], "sphere field rows at 4K")
+
+
 def test_caustic_lab_with_its_photon_maps(R, oracle):
     """Final profile, 32 bounces, spot light (cosines of the cone), gold ring and glass tumbler: the photon list of
     both passes photon by photon, and six samples gathering from them."""

@@ -85,6 +85,35 @@ def test_gather_bit_exact(engine, oracle):
     assert (flux != 0).any()
 
 
+def test_grid_and_gather_at_the_benchmark_sizes(engine, oracle):
+    """2^23 photons over 2^22 buckets, radius 0.0015, one query per pixel of a 1920 x 1080 frame over the table (the
+    map and the queries of the benchmark's photon leg): cell ranges, sorted payload and every flux sum against the
+    oracle, bit for bit, with and without the bucket bits."""
+    n, B, r = 1 << 23, workloads.PHOTON_BUCKETS, 0.0015
+    assert B == 1 << 22
+    ph = workloads.caustic_photons(n, seed=2)
+    grid = engine.PhotonGrid(n, B)
+    grid.build(dev(ph), r, sync=True)
+    offsets, srt = oracle.build_photon_grid(ph, r, B)
+    assert np.array_equal(u32(grid.offsets), offsets)
+    assert np.array_equal(grid.sorted[:n].cpu().numpy().view(np.uint32), srt.view(np.uint32))
+    w, h = 1920, 1080
+    xs = (np.arange(w, dtype=np.float32) + 0.5) / w * 2.0 - 1.0
+    zs = ((np.arange(h, dtype=np.float32) + 0.5) / h * 2.0 - 1.0) * (h / w)
+    qp = np.zeros((h, w, 3), dtype=np.float32)
+    qp[..., 0], qp[..., 2] = xs[None, :], zs[:, None]
+    qn = np.zeros_like(qp)
+    qn[..., 1] = 1.0
+    qp, qn = qp.reshape(-1, 3), qn.reshape(-1, 3)
+    flux = grid.gather(dev(qp), dev(qn)).cpu().numpy()
+    ref = oracle.photon_gather(srt, offsets, B, r, qp, qn, threads=16)
+    assert np.array_equal(flux.view(np.uint32), ref.view(np.uint32))
+    assert (flux != 0).any(axis=1).mean() > 0.5
+    grid.mark_buckets()
+    masked = grid.gather(dev(qp), dev(qn), masked=True).cpu().numpy()
+    assert np.array_equal(masked.view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("n, B", [(20000, 1 << 20), (3000, 2), (500, 32), (40000, 1 << 12)])
 def test_bucket_bits_and_masked_gather(engine, oracle, n, B):
     """The bit-per-bucket map marks exactly the buckets with photons, and a gather that asks the bit
